@@ -1,0 +1,743 @@
+"""TEST INFRASTRUCTURE ONLY -- big-integer restatement of the reference's range-proof path.
+
+This module is part of ``oracle/``: it may be imported only by ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg, as the checker.
+The product (``bulletproofsplus_amd``) never imports it.
+
+What it is
+----------
+A pure-Python (arbitrary precision ``int``) restatement of the reference crate's protocol
+code, written against an abstract *group backend* so that the same protocol code runs over
+
+* ``ShadowGroup``  -- the "dlog shadow": a point is represented by its discrete log w.r.t. the
+  base point, so ``add -> + mod r``, ``scalar-mul -> * mod r``, ``MulVec -> dot product``.
+  Possible because the reference's ``PublicKey::new`` makes every generator a *known* multiple
+  of g (reference ``src/publickey.rs:21-48``).  Gives group-independent known answers.
+* ``WeierstrassGroup`` -- real affine short-Weierstrass (a = 0) arithmetic for BLS12-381 G1 and
+  secp256k1, following the case analysis of reference
+  ``src/secp256k1/building_block/macros.rs:34-152`` (add) and ``:1-32`` (LSB-first
+  double-and-add scalar multiplication).
+
+It is used (1) to pin the C oracle (``oracle/bpp_oracle.c``) and (2) to generate the golden
+fixtures under ``tests/golden/`` (``tests/golden/make_golden.py``).
+
+Parity status: the reference's BLS12-381 arithmetic is the third-party ``mcl_rust``
+(herumi/mcl, un-pinned HEAD, absent from /root/reference), so BLS12-381 *point coordinates*
+are "parity unpinned" by the reference's own tests; they are pinned by BLS12-381 G1 being a
+standard curve plus the generator literal at reference
+``src/bls12_381/building_block/point/point.rs:16``.  secp256k1 primitives are pinned by the
+reference's known-answer tests (``affine_point.rs:231-341``).  Protocol scalars are pinned by
+the dlog-shadow known answers recorded in SURVEY.md section 8c.
+
+Reference files restated (line numbers cite /root/reference/src):
+  util.rs:29-127, publickey.rs:21-52, range/prover.rs:20-42, range/mod.rs:31-510,
+  weighted_inner_product_proof.rs:36-382, bls12_381/building_block/mulvec.rs:20-53,
+  bls12_381/building_block/scalar/prime_field_elem.rs:191-248.
+"""
+
+from __future__ import annotations
+
+# --------------------------------------------------------------------------------------
+# Curve parameters
+# --------------------------------------------------------------------------------------
+
+BLS12_381 = dict(
+    name="bls12_381",
+    # base field
+    p=0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+    # group order (= scalar field Fr)
+    r=0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+    b=4,
+    # generator: decimal literal at reference bls12_381/building_block/point/point.rs:16
+    gx=3685416753713387016781088315183077757961620795782546409894578378688607592378376318836054947676345821548104185464507,
+    gy=1339506544944476473020471379941921221584933875938349620426543736416511423956333506472724655353366534992391756441569,
+    fp_bytes=48,
+)
+
+SECP256K1 = dict(
+    name="secp256k1",
+    # reference secp256k1/building_block/secp256k1/secp256k1.rs:22,26,47-48
+    p=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F,
+    r=0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    b=7,
+    gx=0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+    gy=0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8,
+    fp_bytes=32,
+)
+
+CURVES = {"bls12_381": BLS12_381, "secp256k1": SECP256K1}
+
+
+# --------------------------------------------------------------------------------------
+# Group backends.  A "point" is an opaque value; INF is backend specific.
+# --------------------------------------------------------------------------------------
+
+class ShadowGroup:
+    """Points are discrete logs mod r (reference publickey.rs:23-39 makes this possible)."""
+
+    def __init__(self, r: int):
+        self.r = r
+
+    def base(self):
+        return 1
+
+    def zero(self):
+        return 0
+
+    def is_zero(self, P):
+        return P % self.r == 0
+
+    def add(self, P, Q):
+        return (P + Q) % self.r
+
+    def neg(self, P):
+        return (-P) % self.r
+
+    def mul(self, P, k):
+        return (P * k) % self.r
+
+    def eq(self, P, Q):
+        return (P - Q) % self.r == 0
+
+
+class WeierstrassGroup:
+    """y^2 = x^3 + b over F_p, affine, points are (x, y) tuples or None for infinity."""
+
+    def __init__(self, curve: dict):
+        self.c = curve
+        self.p = curve["p"]
+        self.r = curve["r"]
+        self.b = curve["b"]
+
+    def base(self):
+        return (self.c["gx"], self.c["gy"])
+
+    def zero(self):
+        return None
+
+    def is_zero(self, P):
+        return P is None
+
+    def on_curve(self, P):
+        if P is None:
+            return True
+        x, y = P
+        return (y * y - x * x * x - self.b) % self.p == 0
+
+    def neg(self, P):
+        if P is None:
+            return None
+        return (P[0], (-P[1]) % self.p)
+
+    def add(self, P, Q):
+        # case order of reference macros.rs:42-146
+        p = self.p
+        if P is None and Q is None:
+            return None
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        x1, y1 = P
+        x2, y2 = Q
+        if x1 == x2 and y1 != y2:
+            return None
+        if x1 == x2 and y1 == y2:
+            if x1 == 0 or y1 == 0:  # macros.rs:53-55 (quirk kept; unreachable on these curves)
+                return None
+            m = (3 * x1 * x1) * pow(2 * y1, -1, p) % p
+            x3 = (m * m - 2 * x1) % p
+            y3 = (m * (x1 - x3) - y1) % p
+            return (x3, y3)
+        m = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (m * m - x1 - x2) % p
+        y3 = (-(m * (x3 - x1) + y1)) % p
+        return (x3, y3)
+
+    def mul(self, P, k):
+        # LSB-first double-and-add, reference macros.rs:9-27.  k is NOT reduced: the
+        # reference's secp256k1 tests pass base-field elements as scalars (affine_point.rs:258).
+        res = None
+        q = P
+        while k:
+            if k & 1:
+                res = self.add(res, q)
+            q = self.add(q, q)
+            k >>= 1
+        return res
+
+    def eq(self, P, Q):
+        return P == Q
+
+
+# --------------------------------------------------------------------------------------
+# Scalar helpers (reference src/util.rs)
+# --------------------------------------------------------------------------------------
+
+class Fr:
+    """Scalar-field helper bound to an order r.  All values are ints in [0, r)."""
+
+    def __init__(self, r: int):
+        self.r = r
+
+    def new(self, n: int) -> int:
+        # PrimeFieldElem::new(i32) -> Fr::set_int; negative n maps to r-|n|
+        # (reference bls12_381/building_block/scalar/prime_field_elem.rs:191-195)
+        return n % self.r
+
+    def inv(self, x: int) -> int:
+        return pow(x, -1, self.r)
+
+    def batch_invert(self, xs):
+        # prime_field_elem.rs:239-248: returns (prod of inverses, [inverses])
+        prod = 1
+        inv = []
+        for x in xs:
+            ix = self.inv(x)
+            inv.append(ix)
+            prod = prod * ix % self.r
+        return prod, inv
+
+    def exp_iter_type1(self, x, n):
+        # util.rs:29-32 : 1, x, x^2, ...
+        out, cur = [], 1
+        for _ in range(n):
+            out.append(cur)
+            cur = cur * x % self.r
+        return out
+
+    def exp_iter_type2(self, x, n):
+        # util.rs:34-37 : x, x^2, ...
+        out, cur = [], x % self.r
+        for _ in range(n):
+            out.append(cur)
+            cur = cur * x % self.r
+        return out
+
+    def scalar_exp_vartime(self, x, n):
+        # util.rs:39-52
+        result, aux = 1, x % self.r
+        while n > 0:
+            if n & 1:
+                result = result * aux % self.r
+            n >>= 1
+            aux = aux * aux % self.r
+        return result
+
+    def sum_of_powers_type1(self, x, n):
+        # util.rs:54-79
+        r = self.r
+        if n & (n - 1) or n == 0:
+            if n == 0:
+                # is_power_of_two(0) is false in Rust -> slow path -> empty sum
+                return 0
+            return sum(self.exp_iter_type1(x, n)) % r
+        if n == 1:
+            return 1
+        m = n
+        result = (1 + x) % r
+        factor = x % r
+        while m > 2:
+            factor = factor * factor % r
+            result = (result + factor * result) % r
+            m //= 2
+        return result
+
+    def sum_of_powers_type2(self, x, n):
+        # util.rs:81-106
+        r = self.r
+        if n & (n - 1) or n == 0:
+            if n == 0:
+                return 0
+            return sum(self.exp_iter_type2(x, n)) % r
+        if n == 1:
+            return 1  # util.rs:86 returns new(n) = 1 (NOT x) -- quirk kept
+        m = n
+        result = (x + x * x) % r
+        factor = x % r
+        while m > 2:
+            factor = factor * factor % r
+            result = (result + factor * result) % r
+            m //= 2
+        return result
+
+    def weighted_inner_product(self, a, b, c):
+        # util.rs:117-127
+        out = 0
+        for ai, bi, ci in zip(a, b, c):
+            out = (out + ai * bi * ci) % self.r
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# MulVec (reference bls12_381/building_block/mulvec.rs:20-53)
+# --------------------------------------------------------------------------------------
+
+class MulVec:
+    def __init__(self, G):
+        self.G = G
+        self.scalars = []
+        self.points = []
+
+    def add_scalar(self, s):
+        self.scalars.append(s)
+
+    def add_scalars(self, ss):
+        self.scalars.extend(ss)
+
+    def add_point(self, p):
+        self.points.append(p)
+
+    def add_points(self, ps):
+        self.points.extend(ps)
+
+    def calculate(self):
+        if len(self.scalars) != len(self.points):
+            raise RuntimeError("mulvec: lengths of scalars and points must match")
+        G = self.G
+        acc = G.zero()
+        for s, p in zip(self.scalars, self.points):
+            acc = G.add(acc, G.mul(p, s))
+        return acc
+
+
+# --------------------------------------------------------------------------------------
+# PublicKey / RangeProver (reference publickey.rs, range/prover.rs)
+# --------------------------------------------------------------------------------------
+
+def _i32(v: int) -> int:
+    """Rust ``as i32`` truncation (two's complement wrap)."""
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v & 0x80000000 else v
+
+
+class PublicKey:
+    def __init__(self, G, length: int):
+        # publickey.rs:21-48
+        F = Fr(G.r)
+        g = G.base()
+        self.G = G
+        self.g = g
+        self.h = G.mul(g, F.new(2))
+        self.G_vec = [G.mul(g, F.new(_i32((i + 1) * 3))) for i in range(length)]
+        self.H_vec = [G.mul(g, F.new(_i32((i + 1) * 5))) for i in range(length)]
+
+    def commitment(self, v, gamma):
+        # publickey.rs:50-52
+        G = self.G
+        return G.add(G.mul(self.g, v), G.mul(self.h, gamma))
+
+
+class RangeProver:
+    def __init__(self):
+        self.v_vec = []
+        self.gamma_vec = []
+        self.commitment_vec = []
+
+    def commit(self, pk: PublicKey, v: int, gamma: int):
+        # range/prover.rs:28-42 ; note the `v as i32` truncation at :37
+        F = Fr(pk.G.r)
+        self.v_vec.append(v)
+        self.gamma_vec.append(gamma)
+        self.commitment_vec.append(pk.commitment(F.new(_i32(v)), gamma))
+
+
+# --------------------------------------------------------------------------------------
+# Hard-coded "transcript" constants
+# --------------------------------------------------------------------------------------
+
+class Transcript:
+    """The reference has no Fiat-Shamir transcript; these are its literals."""
+
+    ALPHA_SINGLE = 7      # range/mod.rs:94
+    ALPHA_MULTI = 33      # range/mod.rs:256
+    Y_SINGLE, Z_SINGLE = 7, 7      # range/mod.rs:109-110, :198-199
+    Y_MULTI, Z_MULTI = 12, 23      # range/mod.rs:278-279, :417-418
+    D_L, D_R = 4, 5       # wip.rs:94-95
+    E_ROUND = 7           # wip.rs:131, :353
+    R, S, DELTA, ETA = 33, 44, 88, 123   # wip.rs:175-178
+    E_FINAL = 99          # wip.rs:211, :369
+
+
+# --------------------------------------------------------------------------------------
+# Weighted inner product proof (reference weighted_inner_product_proof.rs)
+# --------------------------------------------------------------------------------------
+
+class WeightedInnerProductProof:
+    def __init__(self, L_vec, R_vec, A, B, r_prime, s_prime, d_prime):
+        self.L_vec, self.R_vec, self.A, self.B = L_vec, R_vec, A, B
+        self.r_prime, self.s_prime, self.d_prime = r_prime, s_prime, d_prime
+
+    @staticmethod
+    def prove(pk: PublicKey, a_vec, b_vec, power_of_y_vec, gamma, commitment, trace=None):
+        # wip.rs:36-227
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        T = Transcript
+        G = list(pk.G_vec)
+        H = list(pk.H_vec)
+        a = list(a_vec)
+        b = list(b_vec)
+        pw = list(power_of_y_vec)
+        alpha = gamma
+        n = len(G)
+        assert len(H) == n and len(a) == n and len(b) == n and len(pw) == n
+        assert n & (n - 1) == 0 and n > 0
+        L_vec, R_vec = [], []
+        while n != 1:
+            n //= 2
+            a1, a2 = a[:n], a[n:]
+            b1, b2 = b[:n], b[n:]
+            y1, y2 = pw[:n], pw[n:]
+            G1, G2 = G[:n], G[n:]
+            H1, H2 = H[:n], H[n:]
+            c_L = F.weighted_inner_product(a1, b2, y1)
+            c_R = F.weighted_inner_product(a2, b1, y2)
+            d_L, d_R = F.new(T.D_L), F.new(T.D_R)
+            y_nhat = y1[n - 1]
+            y_nhat_inv = F.inv(y_nhat)
+            G1_exp = [y_nhat * x % r for x in a2]
+            G2_exp = [y_nhat_inv * x % r for x in a1]
+
+            mv = MulVec(G_)
+            mv.add_scalars(G2_exp); mv.add_scalars(b2); mv.add_scalar(c_L); mv.add_scalar(d_L)
+            mv.add_points(G2); mv.add_points(H1); mv.add_point(pk.g); mv.add_point(pk.h)
+            L = mv.calculate()
+            mv = MulVec(G_)
+            mv.add_scalars(G1_exp); mv.add_scalars(b1); mv.add_scalar(c_R); mv.add_scalar(d_R)
+            mv.add_points(G1); mv.add_points(H2); mv.add_point(pk.g); mv.add_point(pk.h)
+            R = mv.calculate()
+            L_vec.append(L)
+            R_vec.append(R)
+
+            e = F.new(T.E_ROUND)
+            e_inv = F.inv(e)
+            e_sqr = e * e % r
+            e_sqr_inv = e_inv * e_inv % r
+            # wip.rs:137-142 accumulates P, which is never read again: skipped.
+            y_nhat_e_inv = y_nhat * e_inv % r
+            y_nhat_inv_e = y_nhat_inv * e % r
+            na, nb, nG, nH = [], [], [], []
+            for i in range(n):
+                na.append((a1[i] * e + a2[i] * y_nhat_e_inv) % r)
+                nb.append((b1[i] * e_inv + b2[i] * e) % r)
+                mv = MulVec(G_)
+                mv.add_scalar(e_inv); mv.add_scalar(y_nhat_inv_e)
+                mv.add_point(G1[i]); mv.add_point(G2[i])
+                nG.append(mv.calculate())
+                mv = MulVec(G_)
+                mv.add_scalar(e); mv.add_scalar(e_inv)
+                mv.add_point(H1[i]); mv.add_point(H2[i])
+                nH.append(mv.calculate())
+            a, b, pw, G, H = na, nb, y1, nG, nH
+            alpha = (alpha + e_sqr * d_L + e_sqr_inv * d_R) % r
+            if trace is not None:
+                trace.append(dict(n=n, L=L, R=R, a=list(a), b=list(b), G=list(G), H=list(H),
+                                  alpha=alpha))
+
+        rr, s, delta, eta = F.new(T.R), F.new(T.S), F.new(T.DELTA), F.new(T.ETA)
+        rcbsca = (rr * pw[0] * b[0] + s * pw[0] * a[0]) % r
+        rcs = rr * pw[0] * s % r
+        mv = MulVec(G_)
+        mv.add_scalar(rr); mv.add_scalar(s); mv.add_scalar(rcbsca); mv.add_scalar(delta)
+        mv.add_point(G[0]); mv.add_point(H[0]); mv.add_point(pk.g); mv.add_point(pk.h)
+        A = mv.calculate()
+        mv = MulVec(G_)
+        mv.add_scalar(rcs); mv.add_scalar(eta)
+        mv.add_point(pk.g); mv.add_point(pk.h)
+        B = mv.calculate()
+        e = F.new(T.E_FINAL)
+        r_prime = (rr + a[0] * e) % r
+        s_prime = (s + b[0] * e) % r
+        d_prime = (eta + delta * e + alpha * e * e) % r
+        return WeightedInnerProductProof(L_vec, R_vec, A, B, r_prime, s_prime, d_prime)
+
+    def verification_scalars(self, n: int, G_):
+        # wip.rs:330-382 ; returns None for the VerificationError branch at :335-337
+        F = Fr(G_.r)
+        r = G_.r
+        logn = len(self.L_vec)
+        if n != (1 << logn):
+            return None
+        challenges = [F.new(Transcript.E_ROUND) for _ in range(logn)]
+        allinv, challenges_inv = F.batch_invert(challenges)
+        challenges_sqr = [c * c % r for c in challenges]
+        challenges_inv_sqr = [c * c % r for c in challenges_inv]
+        e = F.new(Transcript.E_FINAL)
+        s_vec = [allinv]
+        for i in range(1, n):
+            log_i = i.bit_length() - 1
+            k = 1 << log_i
+            u = challenges_sqr[(logn - 1) - log_i]
+            s_vec.append(s_vec[i - k] * u % r)
+        return challenges_sqr, challenges_inv_sqr, s_vec, e
+
+    def verify_mulvec(self, pk: PublicKey, power_of_y_vec, G_exp_c, H_exp_c, g_exp_c, V_exp_c,
+                      A_prime, V):
+        """wip.rs:238-320: returns the assembled MulVec (or None on the error branch)."""
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        logn = len(self.L_vec)
+        n = 1 << logn
+        y = power_of_y_vec[0]
+        vs = self.verification_scalars(n, G_)
+        if vs is None:
+            return None
+        challenges_sqr, challenges_inv_sqr, s_vec, e = vs
+        s_rev = s_vec[::-1]
+        e_sqr = e * e % r
+        r_prime_e_y = self.r_prime * e * y % r
+        s_prime_e = self.s_prime * e % r
+        Ls_exp = [c * e_sqr % r for c in challenges_sqr]
+        Rs_exp = [c * e_sqr % r for c in challenges_inv_sqr]
+        y_inv_pows = F.exp_iter_type2(F.inv(y), n)
+        G_exp = [(-(s_vec[i]) * y_inv_pows[i] * r_prime_e_y + G_exp_c[i] * e_sqr) % r
+                 for i in range(n)]
+        H_exp = [(-(s_rev[i]) * s_prime_e + H_exp_c[i] * e_sqr) % r for i in range(n)]
+        g_exp = (-self.r_prime * y * self.s_prime + g_exp_c * e_sqr) % r
+        h_exp = (-self.d_prime) % r
+        V_exp = [v * e_sqr % r for v in V_exp_c]
+        mv = MulVec(G_)
+        mv.add_scalar(F.new(1)); mv.add_scalar(e); mv.add_scalar(e_sqr)
+        mv.add_scalar(g_exp); mv.add_scalar(h_exp)
+        mv.add_scalars(Ls_exp); mv.add_scalars(Rs_exp)
+        mv.add_scalars(G_exp); mv.add_scalars(H_exp); mv.add_scalars(V_exp)
+        mv.add_point(self.B); mv.add_point(self.A); mv.add_point(A_prime)
+        mv.add_point(pk.g); mv.add_point(pk.h)
+        mv.add_points(self.L_vec); mv.add_points(self.R_vec)
+        mv.add_points(pk.G_vec); mv.add_points(pk.H_vec); mv.add_points(list(V))
+        return mv
+
+
+# --------------------------------------------------------------------------------------
+# RangeProof (reference range/mod.rs)
+# --------------------------------------------------------------------------------------
+
+class RangeProof:
+    def __init__(self, A, proof: WeightedInnerProductProof):
+        self.A = A
+        self.proof = proof
+
+    # ---- prove -----------------------------------------------------------------------
+    @staticmethod
+    def prove(pk: PublicKey, n: int, prover: RangeProver, trace=None):
+        # range/mod.rs:31-55
+        m = len(prover.v_vec)
+        if m == 1:
+            return RangeProof._prove_single(pk, n, prover.v_vec[0], prover.gamma_vec[0],
+                                            prover.commitment_vec[0], trace)
+        return RangeProof._prove_multiple(pk, n, m, prover.v_vec, prover.gamma_vec,
+                                          prover.commitment_vec, trace)
+
+    @staticmethod
+    def _prove_single(pk, n, v, gamma, commitment, trace=None):
+        # range/mod.rs:80-187
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        T = Transcript
+        assert len(pk.G_vec) == n and len(pk.H_vec) == n
+        alpha = F.new(T.ALPHA_SINGLE)
+        v_bits = []
+        A = G_.mul(pk.h, alpha)
+        for i in range(n):
+            bit = (v >> i) & 1 if i < 64 else 0
+            v_bits.append(bit)
+            pt = pk.G_vec[i] if bit else G_.neg(pk.H_vec[i])
+            A = G_.add(A, pt)
+        y, z = F.new(T.Y_SINGLE), F.new(T.Z_SINGLE)
+        one, two = 1, 2
+        power_of_two = F.exp_iter_type1(2, n)
+        power_of_y = F.exp_iter_type2(y, n)
+        power_of_y_rev = power_of_y[::-1]
+        G_vec_sum = G_.zero()
+        for p in pk.G_vec:
+            G_vec_sum = G_.add(G_vec_sum, p)
+        G_vec_sum_exp = (-z) % r
+        H_exp = [(power_of_two[i] * power_of_y_rev[i] + z) % r for i in range(n)]
+        V_exp = F.scalar_exp_vartime(y, n + 1)
+        g_exp = sum(power_of_y) % r
+        g_exp = g_exp * (z - z * z) % r
+        g_exp = (g_exp - (F.scalar_exp_vartime(two, n) - one) * V_exp * z) % r
+        mv = MulVec(G_)
+        mv.add_scalar(F.new(1)); mv.add_scalar(G_vec_sum_exp); mv.add_scalars(H_exp)
+        mv.add_scalar(g_exp); mv.add_scalar(V_exp)
+        mv.add_point(A); mv.add_point(G_vec_sum); mv.add_points(pk.H_vec)
+        mv.add_point(pk.g); mv.add_point(commitment)
+        A_hat = mv.calculate()
+        nz = (-z) % r
+        one_minus_z = (one - z) % r
+        a_vec = [one_minus_z if bbit else nz for bbit in v_bits]
+        b_vec = [H_exp[i] if v_bits[i] else (H_exp[i] - one) % r for i in range(n)]
+        alpha_hat = (alpha + gamma * V_exp) % r
+        if trace is not None:
+            trace.append(dict(stage="range", A=A, A_hat=A_hat, a_vec=a_vec, b_vec=b_vec,
+                              alpha_hat=alpha_hat))
+        proof = WeightedInnerProductProof.prove(pk, a_vec, b_vec, power_of_y, alpha_hat, A_hat,
+                                                trace)
+        return RangeProof(A, proof)
+
+    @staticmethod
+    def _prove_multiple(pk, n, m, v, gamma_vec, commitment_vec, trace=None):
+        # range/mod.rs:240-403
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        T = Transcript
+        mn = n * m
+        assert len(pk.G_vec) == mn and len(pk.H_vec) == mn
+        alpha = F.new(T.ALPHA_MULTI)
+        v_bits = []
+        A = G_.mul(pk.h, alpha)
+        for i in range(mn):
+            index1, index2 = i % n, i // n
+            bit = (v[index2] >> index1) & 1 if index1 < 64 else 0
+            v_bits.append(bit)
+            pt = pk.G_vec[i] if bit else G_.neg(pk.H_vec[i])
+            A = G_.add(A, pt)
+        y, z = F.new(T.Y_MULTI), F.new(T.Z_MULTI)
+        power_of_two = F.exp_iter_type1(2, n)
+        power_of_y = F.exp_iter_type2(y, mn)
+        power_of_y_rev = power_of_y[::-1]
+        z_sqr = z * z % r
+        power_of_z = F.exp_iter_type2(z_sqr, m)
+        d = [e2 * ez % r for ez in power_of_z for e2 in power_of_two]
+        G_vec_sum_exp = (-z) % r
+        H_exp = [(d[i] * power_of_y_rev[i] + z) % r for i in range(mn)]
+        y_mn1 = F.scalar_exp_vartime(y, mn + 1)
+        V_exp = [pz * y_mn1 % r for pz in power_of_z]
+        g_exp = sum(power_of_y) % r
+        g_exp = g_exp * (z - z_sqr) % r
+        d_sum = sum(d) % r
+        g_exp = (g_exp - d_sum * y_mn1 * z) % r
+        G_vec_sum = G_.zero()
+        for p in pk.G_vec:
+            G_vec_sum = G_.add(G_vec_sum, p)
+        mv = MulVec(G_)
+        mv.add_scalar(F.new(1)); mv.add_scalar(G_vec_sum_exp); mv.add_scalars(H_exp)
+        mv.add_scalar(g_exp); mv.add_scalars(V_exp)
+        mv.add_point(A); mv.add_point(G_vec_sum); mv.add_points(pk.H_vec)
+        mv.add_point(pk.g); mv.add_points(list(commitment_vec))
+        A_hat = mv.calculate()
+        one = 1
+        nz = (-z) % r
+        one_minus_z = (one - z) % r
+        a_vec = [one_minus_z if bbit else nz for bbit in v_bits]
+        b_vec = [H_exp[i] if v_bits[i] else (H_exp[i] - one) % r for i in range(mn)]
+        pzg = 0
+        for pz, gm in zip(power_of_z, gamma_vec):
+            pzg = (pzg + pz * gm) % r
+        alpha_hat = (alpha + pzg * y_mn1) % r
+        if trace is not None:
+            trace.append(dict(stage="range", A=A, A_hat=A_hat, a_vec=a_vec, b_vec=b_vec,
+                              alpha_hat=alpha_hat))
+        proof = WeightedInnerProductProof.prove(pk, a_vec, b_vec, power_of_y, alpha_hat, A_hat,
+                                                trace)
+        return RangeProof(A, proof)
+
+    # ---- verify ----------------------------------------------------------------------
+    def verify_mulvec(self, pk: PublicKey, n: int, commitment_vec):
+        """Returns the final MulVec of range/mod.rs:480-501 (m>1) or wip.rs:297-318 (m==1),
+        or None when verification_scalars takes its error branch."""
+        m = len(commitment_vec)
+        if m == 1:
+            return self._verify_single_mv(pk, n, commitment_vec[0])
+        return self._verify_multiple_mv(pk, n, m, commitment_vec)
+
+    def verify(self, pk: PublicKey, n: int, commitment_vec) -> bool:
+        # range/mod.rs:57-78 ; True = Ok(()), False = Err(VerificationError)
+        mv = self.verify_mulvec(pk, n, commitment_vec)
+        if mv is None:
+            return False
+        return pk.G.is_zero(mv.calculate())
+
+    def _verify_single_mv(self, pk, n, commitment):
+        # range/mod.rs:189-238
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        T = Transcript
+        y, z = F.new(T.Y_SINGLE), F.new(T.Z_SINGLE)
+        one, two = 1, 2
+        power_of_two = F.exp_iter_type1(2, n)
+        power_of_y = F.exp_iter_type2(y, n)
+        power_of_y_rev = power_of_y[::-1]
+        G_exp = [(-z) % r] * n
+        H_exp = [(power_of_two[i] * power_of_y_rev[i] + z) % r for i in range(n)]
+        V_exp = F.scalar_exp_vartime(y, n + 1)
+        g_exp = sum(power_of_y) % r
+        g_exp = g_exp * (z - z * z) % r
+        g_exp = (g_exp - (F.scalar_exp_vartime(two, n) - one) * V_exp * z) % r
+        return self.proof.verify_mulvec(pk, power_of_y, G_exp, H_exp, g_exp, [V_exp], self.A,
+                                        [commitment])
+
+    def _verify_multiple_mv(self, pk, n, m, commitment_vec):
+        # range/mod.rs:405-510
+        G_ = pk.G
+        F = Fr(G_.r)
+        r = G_.r
+        T = Transcript
+        mn = n * m
+        y, z = F.new(T.Y_MULTI), F.new(T.Z_MULTI)
+        minus_z = (-z) % r
+        z_sqr = z * z % r
+        power_of_two = F.exp_iter_type1(2, n)
+        power_of_y = F.exp_iter_type2(y, mn + 1)
+        y_mn1 = power_of_y.pop()
+        power_of_y_rev = power_of_y[::-1]
+        power_of_z = F.exp_iter_type2(z_sqr, m)
+        concat_z_and_2 = [e2 * ez % r for ez in power_of_z for e2 in power_of_two]
+        vs = self.proof.verification_scalars(mn, G_)
+        if vs is None:
+            return None
+        challenges_sqr, challenges_inv_sqr, s_vec, e = vs
+        s_rev = s_vec[::-1]
+        e_inv = F.inv(e)
+        e_sqr = e * e % r
+        e_sqr_inv = F.inv(e_sqr)
+        r_prime, s_prime, d_prime = self.proof.r_prime, self.proof.s_prime, self.proof.d_prime
+        r_prime_e_inv_y = r_prime * e_inv * y % r
+        s_prime_e_inv = s_prime * e_inv % r
+        y_inv_pows = F.exp_iter_type2(F.inv(y), mn)
+        G_exp = [(minus_z - s_vec[i] * y_inv_pows[i] * r_prime_e_inv_y) % r for i in range(mn)]
+        H_exp = [(-s_prime_e_inv * s_rev[i] + (concat_z_and_2[i] * power_of_y_rev[i] + z)) % r
+                 for i in range(mn)]
+        sum_y = F.sum_of_powers_type2(y, mn)
+        sum_2 = F.sum_of_powers_type1(F.new(2), n)
+        sum_z = F.sum_of_powers_type2(z_sqr, m)
+        g_exp = (-r_prime * s_prime * y * e_sqr_inv
+                 + (sum_y * (z - z_sqr) - y_mn1 * z * sum_2 * sum_z)) % r
+        h_exp = (-d_prime * e_sqr_inv) % r
+        V_exp = [pz * y_mn1 % r for pz in power_of_z]
+        mv = MulVec(G_)
+        mv.add_scalar(F.new(1)); mv.add_scalar(e_inv); mv.add_scalar(e_sqr_inv)
+        mv.add_scalar(g_exp); mv.add_scalar(h_exp)
+        mv.add_scalars(challenges_sqr); mv.add_scalars(challenges_inv_sqr)
+        mv.add_scalars(G_exp); mv.add_scalars(H_exp); mv.add_scalars(V_exp)
+        mv.add_point(self.A); mv.add_point(self.proof.A); mv.add_point(self.proof.B)
+        mv.add_point(pk.g); mv.add_point(pk.h)
+        mv.add_points(self.proof.L_vec); mv.add_points(self.proof.R_vec)
+        mv.add_points(pk.G_vec); mv.add_points(pk.H_vec); mv.add_points(list(commitment_vec))
+        return mv
+
+
+# --------------------------------------------------------------------------------------
+# Convenience
+# --------------------------------------------------------------------------------------
+
+def make_group(curve_name: str, shadow: bool):
+    c = CURVES[curve_name]
+    return ShadowGroup(c["r"]) if shadow else WeierstrassGroup(c)
+
+
+def prove_case(curve_name: str, n: int, values, gammas, shadow=True, trace=None):
+    """Runs PublicKey::new(n*m), commit x m, prove.  Returns (pk, prover, proof)."""
+    G = make_group(curve_name, shadow)
+    pk = PublicKey(G, n * len(values))
+    prover = RangeProver()
+    for v, gm in zip(values, gammas):
+        prover.commit(pk, v, gm % G.r)
+    proof = RangeProof.prove(pk, n, prover, trace)
+    return pk, prover, proof
