@@ -1,0 +1,86 @@
+"""ctypes binding of libbpp_amd.so (the C ABI of include/bpp_amd.h).
+
+There is no fallback of any kind: if the shared library is missing or a HIP call fails, the import or
+the call raises.  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C bulletproofsplus_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbpp_amd.so")
+
+BLS12_381_G1 = 0
+SECP256K1 = 1
+CURVE_IDS = {"bls12_381": BLS12_381_G1, "secp256k1": SECP256K1}
+FP_LIMBS = {BLS12_381_G1: 6, SECP256K1: 4}
+
+OK = 0
+VERIFICATION_ERROR = 1
+
+# every symbol include/bpp_amd.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "bpp_init", "bpp_destroy", "bpp_last_error", "bpp_point_words", "bpp_msm", "bpp_msm_batch",
+    "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_commit", "bpp_range_prove", "bpp_range_verify",
+    "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
+    "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
+]
+
+
+class BppError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().bpp_last_error().decode(errors="replace") if _lib is not None else ""
+        super().__init__("%s failed with code %d: %s" % (where, code, msg))
+
+
+_lib = None
+
+
+def lib():
+    """Loads libbpp_amd.so.  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libbpp_amd.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C bulletproofsplus_amd/csrc -j8` (the engine has no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, i32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
+        L.bpp_init.argtypes = [i32, i32, ctypes.POINTER(vp)]
+        L.bpp_destroy.argtypes = [vp]
+        L.bpp_destroy.restype = None
+        L.bpp_last_error.restype = ctypes.c_char_p
+        L.bpp_point_words.argtypes = [i32]
+        L.bpp_msm.argtypes = [vp, vp, vp, sz, vp]
+        L.bpp_msm_batch.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.bpp_scalar_mul_batch.argtypes = [vp, vp, vp, sz, vp]
+        L.bpp_pk_new.argtypes = [vp, sz, vp, vp, vp]
+        L.bpp_commit.argtypes = [vp, vp, u64, vp, vp]
+        L.bpp_range_prove.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
+        L.bpp_range_verify.argtypes = [vp, vp, vp, vp, sz, sz, vp, sz, vp, vp]
+        L.bpp_verifier_create.argtypes = [vp, vp, vp, vp, sz, sz, i32, ctypes.POINTER(vp)]
+        L.bpp_verifier_destroy.argtypes = [vp]
+        L.bpp_verifier_destroy.restype = None
+        L.bpp_verifier_workspace_bytes.argtypes = [vp, sz]
+        L.bpp_verifier_workspace_bytes.restype = sz
+        L.bpp_verifier_msm_len.argtypes = [vp]
+        L.bpp_verifier_msm_len.restype = sz
+        L.bpp_verifier_table_bytes.argtypes = [vp]
+        L.bpp_verifier_table_bytes.restype = sz
+        L.bpp_verifier_run.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp]
+        L.bpp_range_verify_batch.argtypes = [vp, vp, vp, sz, vp]
+        L.bpp_verifier_dominant_kernel.restype = ctypes.c_char_p
+        L.bpp_debug_field_op.argtypes = [vp, i32, i32, vp, vp, sz, vp]
+        L.bpp_debug_point_op.argtypes = [vp, i32, vp, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc < 0:
+        raise BppError(rc, where)
+    return rc

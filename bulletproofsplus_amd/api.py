@@ -1,0 +1,347 @@
+"""Host-side mirror of the reference crate's public API for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (paths relative to /root/reference/src):
+
+  Arith.init()                        bls12_381/building_block/arith.rs:6-19
+  MulVec                              bls12_381/building_block/mulvec.rs:7-53
+  PublicKey(length) / .commitment     publickey.rs:13-52
+  RangeProver / .commit               range/prover.rs:13-42
+  RangeProof.prove / .verify          range/mod.rs:25-78
+  WeightedInnerProductProof (fields)  weighted_inner_product_proof.rs:25-33
+  ProofError                          errors.rs:14-50 (only VerificationError is ever constructed)
+
+plus ``BatchVerifier``, the device-resident batch path the reference does not have.
+
+Data is numpy ``uint64`` in the wire format of include/bpp_amd.h: scalars (..., 4), points (..., 2L+1).
+Python ints are accepted for scalars.  Every call runs HIP kernels; nothing is computed on the CPU
+beyond (de)serialisation.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import BLS12_381_G1, SECP256K1, CURVE_IDS, BppError, check  # noqa: F401
+
+
+class ProofError(Exception):
+    """reference src/errors.rs:14-50"""
+
+
+class VerificationError(ProofError):
+    """ProofError::VerificationError"""
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def scalar_to_wire(x) -> np.ndarray:
+    if isinstance(x, np.ndarray):
+        return np.ascontiguousarray(x, dtype=np.uint64).reshape(4)
+    x = int(x)
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def scalars_to_wire(xs) -> np.ndarray:
+    if isinstance(xs, np.ndarray) and xs.dtype == np.uint64:
+        return np.ascontiguousarray(xs).reshape(-1, 4)
+    out = np.zeros((len(xs), 4), dtype=np.uint64)
+    for i, x in enumerate(xs):
+        out[i] = scalar_to_wire(x)
+    return out
+
+
+def wire_to_int(a) -> int:
+    v = 0
+    for i, w in enumerate(np.asarray(a, dtype=np.uint64).reshape(-1).tolist()):
+        v |= int(w) << (64 * i)
+    return v
+
+
+class Arith:
+    """One context per (curve, device); ``Arith.init()`` mirrors the reference's global one-time init."""
+
+    _ctxs = {}
+
+    def __init__(self, curve=BLS12_381_G1, device=0):
+        if isinstance(curve, str):
+            curve = CURVE_IDS[curve]
+        self.curve = curve
+        self.device = device
+        self.L = _lib.FP_LIMBS[curve]
+        self.PW = 2 * self.L + 1
+        h = ctypes.c_void_p()
+        check(_lib.lib().bpp_init(curve, device, ctypes.byref(h)), "bpp_init")
+        self.handle = h
+
+    @classmethod
+    def init(cls, curve=BLS12_381_G1, device=0) -> "Arith":
+        if isinstance(curve, str):
+            curve = CURVE_IDS[curve]
+        key = (curve, device)
+        if key not in cls._ctxs:
+            cls._ctxs[key] = cls(curve, device)
+        return cls._ctxs[key]
+
+    # Point::zero()
+    def zero_point(self) -> np.ndarray:
+        z = np.zeros(self.PW, dtype=np.uint64)
+        z[2 * self.L] = 1
+        return z
+
+    def is_zero(self, p) -> bool:
+        return int(np.asarray(p).reshape(-1)[2 * self.L]) != 0
+
+    # Point * PrimeFieldElem, n independent pairs
+    def scalar_mul(self, scalars, points) -> np.ndarray:
+        sc = scalars_to_wire(scalars)
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.PW)
+        if sc.shape[0] != pts.shape[0]:
+            raise ValueError("scalar_mul: lengths must match")
+        out = np.zeros((sc.shape[0], self.PW), dtype=np.uint64)
+        check(_lib.lib().bpp_scalar_mul_batch(self.handle, _ptr(sc), _ptr(pts), sc.shape[0], _ptr(out)),
+              "bpp_scalar_mul_batch")
+        return out
+
+
+class MulVec:
+    """reference bls12_381/building_block/mulvec.rs: append scalars, append points, calculate()."""
+
+    def __init__(self, arith: Arith):
+        self.arith = arith
+        self.scalars = []
+        self.points = []
+
+    def add_scalar(self, s):
+        self.scalars.append(scalar_to_wire(s))
+
+    def add_scalars(self, ss):
+        for s in ss:
+            self.add_scalar(s)
+
+    def add_point(self, p):
+        self.points.append(np.ascontiguousarray(p, dtype=np.uint64).reshape(self.arith.PW))
+
+    def add_points(self, ps):
+        for p in np.asarray(ps, dtype=np.uint64).reshape(-1, self.arith.PW):
+            self.add_point(p)
+
+    def calculate(self) -> np.ndarray:
+        if len(self.scalars) != len(self.points):
+            # the reference panics here (mulvec.rs:23-25)
+            raise RuntimeError("mulvec: lengths of scalars and points must match")
+        n = len(self.scalars)
+        sc = np.stack(self.scalars) if n else np.zeros((0, 4), np.uint64)
+        pts = np.stack(self.points) if n else np.zeros((0, self.arith.PW), np.uint64)
+        out = np.zeros(self.arith.PW, dtype=np.uint64)
+        check(_lib.lib().bpp_msm(self.arith.handle, _ptr(sc), _ptr(pts), n, _ptr(out)), "bpp_msm")
+        return out
+
+
+def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
+    """`len(lens)` independent MulVecs in one launch."""
+    sc = scalars_to_wire(scalars)
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, arith.PW)
+    ln = np.ascontiguousarray(lens, dtype=np.uint32)
+    if int(ln.sum()) != sc.shape[0] or sc.shape[0] != pts.shape[0]:
+        raise RuntimeError("mulvec: lengths of scalars and points must match")
+    out = np.zeros((len(ln), arith.PW), dtype=np.uint64)
+    check(_lib.lib().bpp_msm_batch(arith.handle, _ptr(sc), _ptr(pts), _ptr(ln), len(ln), _ptr(out)), "bpp_msm_batch")
+    return out
+
+
+class PublicKey:
+    """reference publickey.rs:13-52.  Fields g, h, G_vec, H_vec as in the reference."""
+
+    def __init__(self, arith: Arith, length: int):
+        self.arith = arith
+        PW = arith.PW
+        self.gh = np.zeros((2, PW), dtype=np.uint64)
+        self.G_vec = np.zeros((max(length, 1), PW), dtype=np.uint64)
+        self.H_vec = np.zeros((max(length, 1), PW), dtype=np.uint64)
+        check(_lib.lib().bpp_pk_new(arith.handle, length, _ptr(self.gh), _ptr(self.G_vec), _ptr(self.H_vec)),
+              "bpp_pk_new")
+        self.G_vec = self.G_vec[:length]
+        self.H_vec = self.H_vec[:length]
+
+    @classmethod
+    def new(cls, arith: Arith, length: int) -> "PublicKey":
+        return cls(arith, length)
+
+    @classmethod
+    def from_points(cls, arith: Arith, gh, G_vec, H_vec) -> "PublicKey":
+        """An arbitrary generator set (the reference only has `new`; used for the 'hard' distribution)."""
+        self = cls.__new__(cls)
+        self.arith = arith
+        self.gh = np.ascontiguousarray(gh, dtype=np.uint64).reshape(2, arith.PW)
+        self.G_vec = np.ascontiguousarray(G_vec, dtype=np.uint64).reshape(-1, arith.PW)
+        self.H_vec = np.ascontiguousarray(H_vec, dtype=np.uint64).reshape(-1, arith.PW)
+        return self
+
+    @property
+    def g(self):
+        return self.gh[0]
+
+    @property
+    def h(self):
+        return self.gh[1]
+
+    def commitment(self, v, gamma) -> np.ndarray:
+        """g * v + h * gamma (publickey.rs:50-52); v, gamma scalars."""
+        mv = MulVec(self.arith)
+        mv.add_scalar(v)
+        mv.add_scalar(gamma)
+        mv.add_point(self.g)
+        mv.add_point(self.h)
+        return mv.calculate()
+
+
+class RangeProver:
+    """reference range/prover.rs:13-42."""
+
+    def __init__(self):
+        self.v_vec = []
+        self.gamma_vec = []
+        self.commitment_vec = []
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def commit(self, pk: PublicKey, v: int, gamma):
+        g = scalar_to_wire(gamma)
+        out = np.zeros(pk.arith.PW, dtype=np.uint64)
+        check(_lib.lib().bpp_commit(pk.arith.handle, _ptr(pk.gh), ctypes.c_uint64(v), _ptr(g), _ptr(out)), "bpp_commit")
+        self.v_vec.append(int(v))
+        self.gamma_vec.append(g)
+        self.commitment_vec.append(out)
+
+
+class WeightedInnerProductProof:
+    """Field holder, reference weighted_inner_product_proof.rs:25-33."""
+
+    def __init__(self, L_vec, R_vec, A, B, r_prime, s_prime, d_prime):
+        self.L_vec, self.R_vec, self.A, self.B = L_vec, R_vec, A, B
+        self.r_prime, self.s_prime, self.d_prime = r_prime, s_prime, d_prime
+
+
+class RangeProof:
+    """reference range/mod.rs:25-78: struct RangeProof { A, proof }."""
+
+    def __init__(self, A, proof: WeightedInnerProductProof):
+        self.A = A
+        self.proof = proof
+
+    # wire record used by the C ABI: points [A, wip.A, wip.B, L.., R..], scalars [r', s', d']
+    def points_wire(self) -> np.ndarray:
+        p = self.proof
+        return np.concatenate([np.stack([self.A, p.A, p.B]), np.asarray(p.L_vec), np.asarray(p.R_vec)]).astype(np.uint64)
+
+    def scalars_wire(self) -> np.ndarray:
+        p = self.proof
+        return np.stack([scalar_to_wire(p.r_prime), scalar_to_wire(p.s_prime), scalar_to_wire(p.d_prime)])
+
+    @classmethod
+    def from_wire(cls, points, scalars) -> "RangeProof":
+        points = np.asarray(points, dtype=np.uint64)
+        k = (points.shape[0] - 3) // 2
+        sc = np.asarray(scalars, dtype=np.uint64).reshape(3, 4)
+        return cls(points[0], WeightedInnerProductProof(points[3:3 + k], points[3 + k:3 + 2 * k], points[1], points[2],
+                                                        sc[0], sc[1], sc[2]))
+
+    @classmethod
+    def prove(cls, pk: PublicKey, n: int, prover: RangeProver) -> "RangeProof":
+        a = pk.arith
+        m = len(prover.v_vec)
+        mn = n * m
+        if m == 0 or mn & (mn - 1):
+            raise AssertionError("n * m must be a power of two")      # wip.rs:67 assert
+        if len(pk.G_vec) != mn or len(pk.H_vec) != mn:
+            raise AssertionError("pk must hold n*m generators")       # range/mod.rs:90-91,252-253 assert_eq
+        k = mn.bit_length() - 1
+        v = np.array(prover.v_vec, dtype=np.uint64)
+        gm = np.stack(prover.gamma_vec)
+        V = np.stack(prover.commitment_vec)
+        pts = np.zeros((3 + 2 * k, a.PW), dtype=np.uint64)
+        sc = np.zeros((3, 4), dtype=np.uint64)
+        G = np.ascontiguousarray(pk.G_vec)
+        H = np.ascontiguousarray(pk.H_vec)
+        check(_lib.lib().bpp_range_prove(a.handle, _ptr(pk.gh), _ptr(G), _ptr(H), n, m, _ptr(v), _ptr(gm), _ptr(V),
+                                         _ptr(pts), _ptr(sc)), "bpp_range_prove")
+        return cls.from_wire(pts, sc)
+
+    def verify(self, pk: PublicKey, n: int, commitment_vec) -> None:
+        """Returns None for Ok(()); raises VerificationError for Err(ProofError::VerificationError)."""
+        a = pk.arith
+        V = np.ascontiguousarray(np.asarray(commitment_vec, dtype=np.uint64).reshape(-1, a.PW))
+        m = V.shape[0]
+        pts = np.ascontiguousarray(self.points_wire())
+        sc = np.ascontiguousarray(self.scalars_wire())
+        k = (pts.shape[0] - 3) // 2
+        G = np.ascontiguousarray(pk.G_vec)
+        H = np.ascontiguousarray(pk.H_vec)
+        rc = check(_lib.lib().bpp_range_verify(a.handle, _ptr(pk.gh), _ptr(G), _ptr(H), n, m, _ptr(pts), k, _ptr(sc),
+                                               _ptr(V)), "bpp_range_verify")
+        if rc != 0:
+            raise VerificationError("VerificationError")
+
+
+class BatchVerifier:
+    """Device-resident batch verification of independent proofs for one (pk, n, m).
+
+    ``verify_wire`` takes host arrays; ``run_device`` takes raw device pointers (e.g. torch tensors'
+    ``data_ptr()``) and is the call the benchmark times."""
+
+    def __init__(self, pk: PublicKey, n: int, m: int, window_bits: int = 13):
+        self.arith = pk.arith
+        self.n, self.m = n, m
+        h = ctypes.c_void_p()
+        G = np.ascontiguousarray(pk.G_vec)
+        H = np.ascontiguousarray(pk.H_vec)
+        check(_lib.lib().bpp_verifier_create(pk.arith.handle, _ptr(pk.gh), _ptr(G), _ptr(H), n, m, window_bits,
+                                             ctypes.byref(h)), "bpp_verifier_create")
+        self.handle = h
+        self.msm_len = _lib.lib().bpp_verifier_msm_len(h)
+        self.table_bytes = _lib.lib().bpp_verifier_table_bytes(h)
+        mn = n * m
+        self.k = mn.bit_length() - 1
+        self.points_per_proof = 3 + 2 * self.k + m
+
+    def close(self):
+        if self.handle:
+            _lib.lib().bpp_verifier_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self, count: int) -> int:
+        return _lib.lib().bpp_verifier_workspace_bytes(self.handle, count)
+
+    def verify_wire(self, points, scalars) -> np.ndarray:
+        """points (count, 3+2k+m, PW) [A, wip.A, wip.B, L.., R.., V..], scalars (count, 3, 4) -> ok (count,) u32"""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.points_per_proof, self.arith.PW)
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
+        count = pts.shape[0]
+        ok = np.zeros(count, dtype=np.uint32)
+        check(_lib.lib().bpp_range_verify_batch(self.handle, _ptr(pts), _ptr(sc), count, _ptr(ok)),
+              "bpp_range_verify_batch")
+        return ok
+
+    def run_device(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,
+                   stream: int = 0, d_challenges: int = 0, d_out_scalars: int = 0, d_out_result: int = 0):
+        check(_lib.lib().bpp_verifier_run(self.handle, d_points, d_scalars, count, d_challenges or None, d_ok,
+                                          d_workspace, workspace_bytes, d_out_scalars or None, d_out_result or None,
+                                          stream or None), "bpp_verifier_run")
+
+
+def proof_record(proof: RangeProof, commitment_vec) -> np.ndarray:
+    """[A, wip.A, wip.B, L.., R.., V..] -- the per-proof point record of the batch verifier."""
+    return np.concatenate([proof.points_wire(), np.asarray(commitment_vec, dtype=np.uint64)])

@@ -1,0 +1,171 @@
+// capi.hip -- the extern "C" boundary of libbpp_amd.so (declared in include/bpp_amd.h).  Thin: argument
+// checks, curve dispatch, then the per-curve implementations (impl_*.hpp, compiled in tu_*.hip).
+// No CPU fallback: every entry point launches HIP kernels on the context's device.
+#include "impl_msm.hpp"
+#include "impl_prove.hpp"
+#include "impl_verify.hpp"
+
+using namespace bpp;
+
+extern "C" const char* bpp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int bpp_init(int curve_id, int device, bpp_ctx** out_ctx) {
+    if (!out_ctx) return fail(BPP_E_ARG, "null out_ctx");
+    if (curve_id != BPP_BLS12_381_G1 && curve_id != BPP_SECP256K1) return fail(BPP_E_ARG, "unknown curve id");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(BPP_E_HIP, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    *out_ctx = new bpp_ctx{curve_id, device};
+    return BPP_OK;
+}
+extern "C" void bpp_destroy(bpp_ctx* ctx) { delete ctx; }
+
+extern "C" int bpp_point_words(int curve_id) {
+    switch (curve_id) {
+        case BPP_BLS12_381_G1: return 2 * 6 + 1;
+        case BPP_SECP256K1: return 2 * 4 + 1;
+        default: return BPP_E_ARG;
+    }
+}
+
+extern "C" int bpp_msm_batch(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, const uint32_t* lens,
+                             size_t count, uint64_t* out) {
+    if (!ctx || !out || (count && !lens)) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::msm_batch(scalars, points, lens, count, out);
+    });
+}
+
+extern "C" int bpp_msm(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t* out) {
+    if (n > 0xffffffffull) return fail(BPP_E_ARG, "n too large");
+    const uint32_t len = (uint32_t)n;
+    return bpp_msm_batch(ctx, scalars, points, &len, 1, out);
+}
+
+extern "C" int bpp_scalar_mul_batch(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n,
+                                    uint64_t* out) {
+    if (!ctx || !out || (n && (!scalars || !points))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::scalar_mul_batch(scalars, points, n, out);
+    });
+}
+
+extern "C" int bpp_pk_new(bpp_ctx* ctx, size_t length, uint64_t* out_gh, uint64_t* out_G, uint64_t* out_H) {
+    if (!ctx || !out_gh || (length && (!out_G || !out_H))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::pk_new(length, out_gh, out_G, out_H);
+    });
+}
+
+extern "C" int bpp_commit(bpp_ctx* ctx, const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out) {
+    if (!ctx || !gh || !gamma || !out) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int { return MsmImpl<decltype(cv)>::commit(gh, v, gamma, out); });
+}
+
+extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
+                                size_t m, const uint64_t* proof_points, size_t k, const uint64_t* proof_scalars,
+                                const uint64_t* V) {
+    if (!ctx || !gh || !G || !H || !proof_points || !proof_scalars || !V) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::range_verify_single(gh, G, H, n, m, proof_points, k, proof_scalars, V);
+    });
+}
+
+extern "C" int bpp_range_prove(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
+                               size_t m, const uint64_t* v, const uint64_t* gamma, const uint64_t* V,
+                               uint64_t* out_points, uint64_t* out_scalars) {
+    if (!ctx || !gh || !G || !H || !v || !gamma || !V || !out_points || !out_scalars)
+        return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        std::string err;
+        int rc = ProveImpl<decltype(cv)>::range_prove(gh, G, H, n, m, v, gamma, V, out_points, out_scalars, err);
+        return rc ? fail(rc, err) : BPP_OK;
+    });
+}
+
+// ---- batch verifier ------------------------------------------------------------------------------------
+extern "C" int bpp_verifier_create(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
+                                   size_t m, int window_bits, bpp_verifier** out) {
+    if (!ctx || !gh || !G || !H || !out) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::create(*ctx, gh, G, H, n, m, window_bits, out);
+    });
+}
+extern "C" void bpp_verifier_destroy(bpp_verifier* v) { delete v; }
+
+extern "C" size_t bpp_verifier_workspace_bytes(const bpp_verifier* v, size_t count) {
+    if (!v) return 0;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::ws_layout(v->s, count).total;
+        return 0;
+    });
+    return r;
+}
+extern "C" size_t bpp_verifier_msm_len(const bpp_verifier* v) { return v ? v->s.N : 0; }
+extern "C" size_t bpp_verifier_table_bytes(const bpp_verifier* v) { return v ? v->table_bytes : 0; }
+extern "C" const char* bpp_verifier_dominant_kernel(void) { return "k_fixed_msm"; }
+
+extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace,
+                                size_t workspace_bytes, uint64_t* d_out_scalars, uint64_t* d_out_result,
+                                void* stream) {
+    if (!v || !d_points || !d_scalars || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    if (count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count too large for one launch");
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::run(v, d_points, d_scalars, count, d_challenges, d_ok, d_workspace,
+                                             workspace_bytes, d_out_scalars, d_out_result,
+                                             static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int bpp_range_verify_batch(bpp_verifier* v, const uint64_t* points, const uint64_t* scalars, size_t count,
+                                      uint32_t* out_ok) {
+    if (!v || !points || !scalars || !out_ok) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(v->ctx.device));
+    const size_t pw = (size_t)bpp_point_words(v->ctx.curve) * 8;
+    DevBuf dp, ds, dok, dws;
+    HIPCHK(dp.alloc(count * v->s.NV * pw));
+    HIPCHK(ds.alloc(count * 3 * 32));
+    HIPCHK(dok.alloc(count * 4));
+    const size_t wsb = bpp_verifier_workspace_bytes(v, count);
+    HIPCHK(dws.alloc(wsb));
+    HIPCHK(hipMemcpy(dp.p, points, count * v->s.NV * pw, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ds.p, scalars, count * 3 * 32, hipMemcpyHostToDevice));
+    int rc = bpp_verifier_run(v, static_cast<const uint64_t*>(dp.p), static_cast<const uint64_t*>(ds.p), count, nullptr,
+                              dok.u32(), dws.p, wsb, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
+    return BPP_OK;
+}
+
+// ---- device-side unit-test hooks (tests/ check the device field / group primitives against a CPU checker) --
+// field: 0 = base field, 1 = scalar field; op: 0 mul, 1 add, 2 sub, 3 inv, 4 sqr, 5 neg
+// a, b, out: n elements of N 32-bit words (N = 12 for BLS12-381 Fp, else 8), host pointers
+extern "C" int bpp_debug_field_op(bpp_ctx* ctx, int field, int op, const uint32_t* a, const uint32_t* b, size_t n,
+                                  uint32_t* out) {
+    if (!ctx || !a || !b || !out) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::debug_field_op(field, op, a, b, n, out);
+    });
+}
+// op: 0 add, 1 madd, 2 dbl(a), 3 madd(2a, b), 4 add(2a, 2b); wire points, host pointers
+extern "C" int bpp_debug_point_op(bpp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n,
+                                  uint64_t* out) {
+    if (!ctx || !a || !b || !out) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::debug_point_op(op, a, b, n, out);
+    });
+}

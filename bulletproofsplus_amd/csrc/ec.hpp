@@ -1,0 +1,303 @@
+// ec.hpp -- short-Weierstrass (a = 0) group law for BLS12-381 G1 and secp256k1, host + gfx950.
+//
+// Replaces, on the hot path, the reference's `Point` (mcl G1: add/sub/mul/neg/zero/is_zero/eq,
+// reference src/bls12_381/building_block/point/point.rs:34-117) and the secp256k1 `AffinePoint`
+// (case analysis of reference src/secp256k1/building_block/macros.rs:42-146).
+//
+// Every addition here is COMPLETE for the cases the reference distinguishes: inf + Q, P + inf,
+// P + (-P) -> inf, P + P -> doubling.  This matters on the parity vectors: the reference's generators
+// are small multiples of g (G_4 = H_2 = 15 g, reference src/publickey.rs:31,38), so equal and opposite
+// points do meet inside an MSM.
+//
+// Memory images (all little-endian 32-bit words, Fp in Montgomery form, see field.hpp):
+//   affine  : x | y                (2 N words)   x = y = 0 encodes the point at infinity
+//             (not on y^2 = x^3 + b for b != 0, so the encoding is unambiguous)
+//   jacobian: X | Y | Z            (3 N words)   Z = 0 encodes infinity
+//   wire    : x | y | inf          (2 N + 2 words = (2 L + 1) u64), canonical (non-Montgomery) --
+//             the C-ABI format of include/bpp_amd.h
+#pragma once
+#include "field.hpp"
+
+namespace bpp {
+
+struct Bls12381 {
+    using Fp = BlsFp;
+    using Fr = BlsFr;
+    using K = Bls12381Consts;
+    static constexpr int ID = 0;
+};
+struct Secp256k1 {
+    using Fp = SecpFp;
+    using Fr = SecpFr;
+    using K = Secp256k1Consts;
+    static constexpr int ID = 1;
+};
+
+template <class C>
+struct Aff {
+    Fe<typename C::Fp> x, y;
+    BPP_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+};
+
+template <class C>
+struct Jac {
+    Fe<typename C::Fp> X, Y, Z;
+    BPP_HD bool is_inf() const { return Z.is_zero(); }
+};
+
+template <class C>
+BPP_HD Aff<C> aff_inf() {
+    Aff<C> r;
+    r.x = Fe<typename C::Fp>::zero();
+    r.y = Fe<typename C::Fp>::zero();
+    return r;
+}
+template <class C>
+BPP_HD Jac<C> jac_inf() {
+    Jac<C> r;
+    r.X = Fe<typename C::Fp>::one();
+    r.Y = Fe<typename C::Fp>::one();
+    r.Z = Fe<typename C::Fp>::zero();
+    return r;
+}
+template <class C>
+BPP_HD Jac<C> jac_from_aff(const Aff<C>& p) {
+    if (p.is_inf()) return jac_inf<C>();
+    Jac<C> r;
+    r.X = p.x;
+    r.Y = p.y;
+    r.Z = Fe<typename C::Fp>::one();
+    return r;
+}
+template <class C>
+BPP_HD Aff<C> aff_generator() {
+    Aff<C> g;
+#pragma unroll
+    for (int i = 0; i < C::Fp::NL; i++) {
+        g.x.l[i] = C::K::GX[i];
+        g.y.l[i] = C::K::GY[i];
+    }
+    return g;
+}
+template <class C>
+BPP_HD Aff<C> aff_neg(const Aff<C>& p) {
+    Aff<C> r;
+    r.x = p.x;
+    r.y = fe_neg(p.y);  // -0 = 0 keeps the infinity encoding
+    return r;
+}
+template <class C>
+BPP_HD Jac<C> jac_neg(const Jac<C>& p) {
+    Jac<C> r = p;
+    r.Y = fe_neg(p.Y);
+    return r;
+}
+
+// y^2 == x^3 + b
+template <class C>
+BPP_HD bool aff_on_curve(const Aff<C>& p) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf()) return true;
+    F b;
+#pragma unroll
+    for (int i = 0; i < C::Fp::NL; i++) b.l[i] = C::K::B[i];
+    F lhs = fe_sqr(p.y);
+    F rhs = fe_add(fe_mul(fe_sqr(p.x), p.x), b);
+    return lhs == rhs;
+}
+
+// dbl-2009-l (a = 0): 2M + 5S.  Y = 0 has no points on these prime-order curves.
+template <class C>
+BPP_HD Jac<C> jac_dbl(const Jac<C>& p) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf()) return p;
+    F A = fe_sqr(p.X);
+    F B = fe_sqr(p.Y);
+    F Cc = fe_sqr(B);
+    F t = fe_sqr(fe_add(p.X, B));
+    t = fe_sub(fe_sub(t, A), Cc);
+    F D = fe_dbl(t);
+    F E = fe_add(fe_dbl(A), A);
+    F Fq = fe_sqr(E);
+    Jac<C> r;
+    r.X = fe_sub(Fq, fe_dbl(D));
+    F C8 = fe_dbl(fe_dbl(fe_dbl(Cc)));
+    r.Y = fe_sub(fe_mul(E, fe_sub(D, r.X)), C8);
+    r.Z = fe_dbl(fe_mul(p.Y, p.Z));
+    return r;
+}
+
+// doubling of an affine point (Z = 1): 1M + 5S
+template <class C>
+BPP_HD Jac<C> aff_dbl(const Aff<C>& p) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf()) return jac_inf<C>();
+    F A = fe_sqr(p.x);
+    F B = fe_sqr(p.y);
+    F Cc = fe_sqr(B);
+    F t = fe_sqr(fe_add(p.x, B));
+    t = fe_sub(fe_sub(t, A), Cc);
+    F D = fe_dbl(t);
+    F E = fe_add(fe_dbl(A), A);
+    F Fq = fe_sqr(E);
+    Jac<C> r;
+    r.X = fe_sub(Fq, fe_dbl(D));
+    F C8 = fe_dbl(fe_dbl(fe_dbl(Cc)));
+    r.Y = fe_sub(fe_mul(E, fe_sub(D, r.X)), C8);
+    r.Z = fe_dbl(p.y);
+    return r;
+}
+
+// add-2007-bl with the reference's case analysis (macros.rs:42-146): 11M + 5S
+template <class C>
+BPP_HD Jac<C> jac_add(const Jac<C>& p, const Jac<C>& q) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf()) return q;
+    if (q.is_inf()) return p;
+    F Z1Z1 = fe_sqr(p.Z);
+    F Z2Z2 = fe_sqr(q.Z);
+    F U1 = fe_mul(p.X, Z2Z2);
+    F U2 = fe_mul(q.X, Z1Z1);
+    F S1 = fe_mul(fe_mul(p.Y, q.Z), Z2Z2);
+    F S2 = fe_mul(fe_mul(q.Y, p.Z), Z1Z1);
+    F H = fe_sub(U2, U1);
+    F rr = fe_sub(S2, S1);
+    if (H.is_zero()) {
+        if (rr.is_zero()) return jac_dbl(p);  // same point
+        return jac_inf<C>();                   // vertical line
+    }
+    rr = fe_dbl(rr);
+    F I = fe_sqr(fe_dbl(H));
+    F J = fe_mul(H, I);
+    F V = fe_mul(U1, I);
+    Jac<C> r;
+    r.X = fe_sub(fe_sub(fe_sqr(rr), J), fe_dbl(V));
+    r.Y = fe_sub(fe_mul(rr, fe_sub(V, r.X)), fe_dbl(fe_mul(S1, J)));
+    F zz = fe_sqr(fe_add(p.Z, q.Z));
+    r.Z = fe_mul(fe_sub(fe_sub(zz, Z1Z1), Z2Z2), H);
+    return r;
+}
+
+// mixed addition, madd-2007-bl (Z2 = 1): 7M + 4S, same case analysis
+template <class C>
+BPP_HD Jac<C> jac_madd(const Jac<C>& p, const Aff<C>& q) {
+    using F = Fe<typename C::Fp>;
+    if (q.is_inf()) return p;
+    if (p.is_inf()) return jac_from_aff(q);
+    F Z1Z1 = fe_sqr(p.Z);
+    F U2 = fe_mul(q.x, Z1Z1);
+    F S2 = fe_mul(fe_mul(q.y, p.Z), Z1Z1);
+    F H = fe_sub(U2, p.X);
+    F rr = fe_sub(S2, p.Y);
+    if (H.is_zero()) {
+        if (rr.is_zero()) return aff_dbl(q);
+        return jac_inf<C>();
+    }
+    rr = fe_dbl(rr);
+    F HH = fe_sqr(H);
+    F I = fe_dbl(fe_dbl(HH));
+    F J = fe_mul(H, I);
+    F V = fe_mul(p.X, I);
+    Jac<C> r;
+    r.X = fe_sub(fe_sub(fe_sqr(rr), J), fe_dbl(V));
+    r.Y = fe_sub(fe_mul(rr, fe_sub(V, r.X)), fe_dbl(fe_mul(p.Y, J)));
+    F zh = fe_sqr(fe_add(p.Z, H));
+    r.Z = fe_sub(fe_sub(zh, Z1Z1), HH);
+    return r;
+}
+
+template <class C>
+BPP_HD Aff<C> jac_to_aff(const Jac<C>& p) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf()) return aff_inf<C>();
+    F zi = fe_inv(p.Z);
+    F zi2 = fe_sqr(zi);
+    Aff<C> r;
+    r.x = fe_mul(p.X, zi2);
+    r.y = fe_mul(p.Y, fe_mul(zi2, zi));
+    return r;
+}
+
+// Same group element?  (cross-multiplied comparison, no inversion)
+template <class C>
+BPP_HD bool jac_eq(const Jac<C>& p, const Jac<C>& q) {
+    using F = Fe<typename C::Fp>;
+    if (p.is_inf() || q.is_inf()) return p.is_inf() && q.is_inf();
+    F Z1Z1 = fe_sqr(p.Z), Z2Z2 = fe_sqr(q.Z);
+    if (fe_mul(p.X, Z2Z2) != fe_mul(q.X, Z1Z1)) return false;
+    return fe_mul(fe_mul(p.Y, q.Z), Z2Z2) == fe_mul(fe_mul(q.Y, p.Z), Z1Z1);
+}
+
+// ---- memory images ---------------------------------------------------------------------------------
+template <class C>
+BPP_HD Aff<C> aff_load(const uint32_t* w) {
+    Aff<C> r;
+    r.x = fe_load<typename C::Fp>(w);
+    r.y = fe_load<typename C::Fp>(w + C::Fp::N);
+    return r;
+}
+template <class C>
+BPP_HD void aff_store(const Aff<C>& p, uint32_t* w) {
+    fe_store(p.x, w);
+    fe_store(p.y, w + C::Fp::N);
+}
+template <class C>
+BPP_HD Jac<C> jac_load(const uint32_t* w) {
+    Jac<C> r;
+    r.X = fe_load<typename C::Fp>(w);
+    r.Y = fe_load<typename C::Fp>(w + C::Fp::N);
+    r.Z = fe_load<typename C::Fp>(w + 2 * C::Fp::N);
+    return r;
+}
+template <class C>
+BPP_HD void jac_store(const Jac<C>& p, uint32_t* w) {
+    fe_store(p.X, w);
+    fe_store(p.Y, w + C::Fp::N);
+    fe_store(p.Z, w + 2 * C::Fp::N);
+}
+
+// wire (canonical x | y | inf:u64) -> affine.  Returns false when a coordinate is >= p or the point is
+// not on the curve (the reference has no such check: mcl/BigUint values are valid by construction).
+template <class C>
+BPP_HD bool aff_from_wire(const uint32_t* w, Aff<C>& out) {
+    constexpr int N = C::Fp::N;
+    if (w[2 * N] | w[2 * N + 1]) {
+        out = aff_inf<C>();
+        return true;
+    }
+    if (!words_lt_mod<typename C::Fp>(w) || !words_lt_mod<typename C::Fp>(w + N)) return false;
+    out.x = fe_from_canonical<typename C::Fp>(w);
+    out.y = fe_from_canonical<typename C::Fp>(w + N);
+    if (out.is_inf()) return false;  // (0,0) is not a curve point
+    return aff_on_curve(out);
+}
+template <class C>
+BPP_HD void aff_to_wire(const Aff<C>& p, uint32_t* w) {
+    constexpr int N = C::Fp::N;
+    if (p.is_inf()) {
+#pragma unroll
+        for (int i = 0; i < 2 * N + 2; i++) w[i] = 0;
+        w[2 * N] = 1;
+        return;
+    }
+    fe_to_canonical(p.x, w);
+    fe_to_canonical(p.y, w + N);
+    w[2 * N] = 0;
+    w[2 * N + 1] = 0;
+}
+
+// scalar * point, MSB-first double-and-add over `nbits` bits of the canonical scalar words.
+// Same group element as the reference's LSB-first loop (macros.rs:9-27) / mcl's G1::mul.
+template <class C>
+BPP_HD Jac<C> aff_mul_words(const Aff<C>& p, const uint32_t* k, int nwords) {
+    Jac<C> acc = jac_inf<C>();
+    int top = nwords * 32 - 1;
+    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1u)) top--;
+    for (int i = top; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1u) acc = jac_madd(acc, p);
+    }
+    return acc;
+}
+
+}  // namespace bpp

@@ -1,0 +1,323 @@
+// field.hpp -- Montgomery prime-field arithmetic for gfx950 (and the host side of the same library).
+//
+// One template serves every field of the engine (constants_gen.h): BLS12-381 Fp / Fr and
+// secp256k1 Fp / Fr.  On the hot path it replaces what the reference obtains from mcl's Fp/Fr
+// (reference src/bls12_381/building_block/scalar/prime_field_elem.rs:51-248 -> mcl_rust) and from
+// num-bigint (reference src/secp256k1/building_block/field/prime_field_elem.rs:251-281, :339-392).
+//
+// Representation (chosen for CDNA4, not translated from anything):
+//   * in REGISTERS an element is NL unsaturated 30-bit limbs (13 for the 381-bit field, 9 for the
+//     255/256-bit fields), fully reduced (< p) and normalised (every limb < 2^30), in Montgomery form
+//     with R = 2^(30*NL).
+//   * in MEMORY (HBM tables, proofs, wire) it is N packed 32-bit words (12 / 8) of the same value.
+// Why 30-bit limbs: the only wide multiplier on gfx950 is v_mad_u64_u32 (32x32+64 -> 64).  It has a
+// carry-OUT but no carry-IN, and on gfx90a+/gfx950 a VALU carry written to VCC/SGPR needs two wait
+// states before a VALU instruction may read it, so a saturated 32-bit-limb schedule costs >= 3 issue
+// slots per limb product.  With 30-bit limbs a 64-bit column accumulator absorbs all NL <= 13
+// products of a column (13 * 2^60 < 2^64) with no carry handling at all: one v_mad_u64_u32 per limb
+// product, plus one shift + one mask per column.  No MFMA: there is no carry chain in the matrix pipe.
+#pragma once
+#include <stdint.h>
+#include "constants_gen.h"
+
+#if defined(__HIPCC__)
+#define BPP_HD __host__ __device__ __forceinline__
+#else
+#define BPP_HD inline
+#endif
+
+namespace bpp {
+
+constexpr int LIMB_BITS = 30;
+constexpr uint32_t LIMB_MASK = (1u << LIMB_BITS) - 1u;
+
+template <class P>
+struct Fe {
+    static constexpr int NL = P::NL;
+    uint32_t l[NL];
+
+    BPP_HD static Fe zero() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = 0;
+        return r;
+    }
+    BPP_HD static Fe one() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = P::ONE[i];
+        return r;
+    }
+    BPP_HD static Fe r2() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.l[i] = P::R2[i];
+        return r;
+    }
+    BPP_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) o |= l[i];
+        return o == 0;
+    }
+    BPP_HD bool operator==(const Fe& b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) o |= l[i] ^ b.l[i];
+        return o == 0;
+    }
+    BPP_HD bool operator!=(const Fe& b) const { return !(*this == b); }
+};
+
+// a in [0, 2p), limbs normalised  ->  a mod p
+template <class P>
+BPP_HD void fe_cond_sub_p(Fe<P>& a) {
+    constexpr int NL = P::NL;
+    uint32_t d[NL];
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)P::MOD[i] + borrow;
+        d[i] = (uint32_t)t & LIMB_MASK;
+        borrow = t >> LIMB_BITS;  // 0 or -1
+    }
+    const bool take = (borrow == 0);
+#pragma unroll
+    for (int i = 0; i < NL; i++) a.l[i] = take ? d[i] : a.l[i];
+}
+
+template <class P>
+BPP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    Fe<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t t = a.l[i] + b.l[i] + c;
+        r.l[i] = t & LIMB_MASK;
+        c = t >> LIMB_BITS;
+    }
+    // a + b < 2p < 2^(30 NL): no carry out of the top limb
+    fe_cond_sub_p(r);
+    return r;
+}
+
+template <class P>
+BPP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    Fe<P> r;
+    int32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] + borrow;
+        r.l[i] = (uint32_t)t & LIMB_MASK;
+        borrow = t >> LIMB_BITS;
+    }
+    const uint32_t mask = (uint32_t)borrow;  // all ones when a < b
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        uint32_t t = r.l[i] + (P::MOD[i] & mask) + c;
+        r.l[i] = t & LIMB_MASK;
+        c = t >> LIMB_BITS;
+    }
+    return r;
+}
+
+template <class P>
+BPP_HD Fe<P> fe_neg(const Fe<P>& a) {
+    return fe_sub(Fe<P>::zero(), a);
+}
+
+template <class P>
+BPP_HD Fe<P> fe_dbl(const Fe<P>& a) {
+    return fe_add(a, a);
+}
+
+// Montgomery reduction of a 2*NL-limb normalised product T: returns T * R^-1 mod p.
+// Column-wise (product scanning): column k sums at most NL products < 2^60 plus a 30-bit limb and a
+// carry < 2^35, so the 64-bit accumulator cannot overflow.
+template <class P>
+BPP_HD Fe<P> fe_mont_reduce(const uint32_t* T) {
+    constexpr int NL = P::NL;
+    uint32_t m[NL];
+    Fe<P> r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        acc += T[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::MOD[k - i];
+        m[k] = ((uint32_t)acc * P::INV) & LIMB_MASK;
+        acc += (uint64_t)m[k] * P::MOD[0];
+        acc >>= LIMB_BITS;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL; k++) {
+        acc += T[k];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P::MOD[k - i];
+        r.l[k - NL] = (uint32_t)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    // (T + m p) / R < 2p < 2^(30 NL)  =>  acc == 0 here
+    fe_cond_sub_p(r);
+    return r;
+}
+
+// Montgomery product a*b*R^-1 mod p: NL^2 v_mad_u64_u32 for the product, NL^2 + NL for the reduction.
+template <class P>
+BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    uint32_t T[2 * NL];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++)
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+        T[k] = (uint32_t)acc & LIMB_MASK;
+        acc >>= LIMB_BITS;
+    }
+    T[2 * NL - 1] = (uint32_t)acc;
+    return fe_mont_reduce<P>(T);
+}
+
+// Montgomery square: the NL(NL-1)/2 cross products are computed once and doubled.
+template <class P>
+BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+    constexpr int NL = P::NL;
+    uint32_t T[2 * NL];
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; k++) {
+        uint64_t acc = 0;
+        // pairs i < j, i + j = k
+#pragma unroll
+        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (uint64_t)a.l[i] * a.l[k - i];
+        acc <<= 1;  // <= 6 * 2^60 * 2 < 2^64
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        acc += carry;
+        T[k] = (uint32_t)acc & LIMB_MASK;
+        carry = acc >> LIMB_BITS;
+    }
+    T[2 * NL - 1] = (uint32_t)carry;
+    return fe_mont_reduce<P>(T);
+}
+
+// ---- memory / wire formats -----------------------------------------------------------------------
+
+// N packed 32-bit words (value < 2^(32N), expected < p) -> NL 30-bit limbs.  Pure bit shuffling.
+template <class P>
+BPP_HD Fe<P> fe_unpack(const uint32_t* w) {
+    constexpr int NL = P::NL, N = P::N;
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = LIMB_BITS * i;
+        const int wi = bit >> 5, s = bit & 31;
+        uint32_t v = (wi < N) ? (w[wi] >> s) : 0u;
+        if (s > 32 - LIMB_BITS && wi + 1 < N) v |= w[wi + 1] << (32 - s);
+        r.l[i] = v & LIMB_MASK;
+    }
+    return r;
+}
+
+// NL 30-bit limbs (value < 2^(32N)) -> N packed 32-bit words
+template <class P>
+BPP_HD void fe_pack(const Fe<P>& a, uint32_t* w) {
+    constexpr int NL = P::NL, N = P::N;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const int bit = 32 * j;
+        const int li = bit / LIMB_BITS, o = bit % LIMB_BITS;
+        uint32_t v = a.l[li] >> o;
+        if (li + 1 < NL) v |= a.l[li + 1] << (LIMB_BITS - o);
+        if (2 * LIMB_BITS - o < 32 && li + 2 < NL) v |= a.l[li + 2] << (2 * LIMB_BITS - o);
+        w[j] = v;
+    }
+}
+
+// is the N-word canonical value < p ?
+template <class P>
+BPP_HD bool words_lt_mod(const uint32_t* w) {
+    // compare from the top word down
+    for (int i = P::N - 1; i >= 0; i--) {
+        if (w[i] < P::MODW[i]) return true;
+        if (w[i] > P::MODW[i]) return false;
+    }
+    return false;
+}
+
+// canonical words (any value < 2^(32N); values >= p are reduced, as PrimeFieldElem::new does for
+// BigUint inputs, reference src/secp256k1/building_block/field/prime_field_elem.rs:236-246) -> Montgomery
+template <class P>
+BPP_HD Fe<P> fe_from_canonical(const uint32_t* w) {
+    Fe<P> t = fe_unpack<P>(w);
+    // value < 2^(32N) < 2^(30 NL): T = t * R2 as a plain product, then one Montgomery reduction.
+    // fe_mul requires a normalised operand but not a reduced one: (t*R2 + m p)/R < p * (t/R + 1) < 2p.
+    return fe_mul(t, Fe<P>::r2());
+}
+
+template <class P>
+BPP_HD void fe_to_canonical(const Fe<P>& a, uint32_t* w) {
+    uint32_t T[2 * P::NL];
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) T[i] = a.l[i];
+#pragma unroll
+    for (int i = P::NL; i < 2 * P::NL; i++) T[i] = 0;
+    Fe<P> t = fe_mont_reduce<P>(T);
+    fe_pack(t, w);
+}
+
+// Montgomery-form element <-> its packed memory image (no arithmetic, only repacking)
+template <class P>
+BPP_HD Fe<P> fe_load(const uint32_t* w) {
+    return fe_unpack<P>(w);
+}
+template <class P>
+BPP_HD void fe_store(const Fe<P>& a, uint32_t* w) {
+    fe_pack(a, w);
+}
+
+template <class P>
+BPP_HD Fe<P> fe_from_u32(uint32_t x) {
+    Fe<P> t = Fe<P>::zero();
+    t.l[0] = x & LIMB_MASK;
+    t.l[1] = x >> LIMB_BITS;
+    return fe_mul(t, Fe<P>::r2());
+}
+
+// PrimeFieldElem::new(i32): negative n -> p - |n|
+// (reference src/bls12_381/building_block/scalar/prime_field_elem.rs:191-195, Fr::set_int)
+template <class P>
+BPP_HD Fe<P> fe_from_i32(int32_t n) {
+    if (n >= 0) return fe_from_u32<P>((uint32_t)n);
+    return fe_neg(fe_from_u32<P>((uint32_t)(-(int64_t)n)));
+}
+
+// a^(p-2) by square-and-multiply over the bits of p-2 (a = 0 -> 0).  Same field element as the
+// reference's Fr::inv (mcl) / ext-Euclid safe_inv (field/prime_field_elem.rs:339-392).
+template <class P>
+BPP_HD Fe<P> fe_inv(const Fe<P>& a) {
+    Fe<P> acc = Fe<P>::one();
+    for (int i = P::BITS - 1; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((P::PM2[i >> 5] >> (i & 31)) & 1u) acc = fe_mul(acc, a);
+    }
+    return acc;
+}
+
+// a^n for a small exponent (reference src/util.rs:39-52 scalar_exp_vartime)
+template <class P>
+BPP_HD Fe<P> fe_pow_u64(const Fe<P>& a, uint64_t n) {
+    Fe<P> result = Fe<P>::one(), aux = a;
+    while (n > 0) {
+        if (n & 1) result = fe_mul(result, aux);
+        n >>= 1;
+        aux = fe_sqr(aux);
+    }
+    return result;
+}
+
+}  // namespace bpp

@@ -1,0 +1,133 @@
+// impl_verify.hpp -- the batch verifier (bpp_verifier_*): window tables in HBM + one pass of the hot path
+// over a device-resident batch.  One instantiation per curve (tu_verify_*.hip).
+#pragma once
+#include "host_util.hpp"
+
+struct bpp_verifier {
+    bpp_ctx ctx;
+    bpp::VerifyShape s;
+    bpp::DevBuf table;       // window tables
+    bpp::DevBuf challenges;  // default challenges
+    size_t table_bytes = 0;
+};
+
+namespace bpp {
+
+inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
+    // aim at ~2^18 resident threads; at least one block, at most one generator per thread
+    size_t tpp = ((size_t)1 << 18) / (count ? count : 1);
+    tpp = std::max<size_t>(FIXED_BLOCK, std::min<size_t>(tpp, s.NF));
+    unsigned b = cdiv(tpp, FIXED_BLOCK);
+    return std::max(1u, std::min(b, cdiv(s.NF, FIXED_BLOCK)));
+}
+
+struct WsLayout {
+    size_t pts, bad, scalars, fpart, vpart, total;
+};
+
+template <class C>
+struct VerifyImpl {
+    static constexpr int N = C::Fp::N;
+    static constexpr int WW = 2 * N + 2;
+    static constexpr int PW = WW / 2;
+
+    static WsLayout ws_layout(const VerifyShape& s, size_t count) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        WsLayout w;
+        size_t o = 0;
+        w.pts = o;
+        o += al(count * s.NV * 2 * N * 4);
+        w.bad = o;
+        o += al(count * 4);
+        w.scalars = o;
+        o += al(count * (size_t)s.N * 32);
+        w.fpart = o;
+        o += al(count * blocks_per_proof(s, count) * 3 * N * 4);
+        w.vpart = o;
+        o += al(count * 3 * N * 4);
+        w.total = o;
+        return w;
+    }
+
+    static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
+                      int window_bits, bpp_verifier** out) {
+        VerifyShape s;
+        int rc = make_shape(n, m, window_bits, s);
+        if (rc) return rc;
+        std::vector<uint64_t> fixed((size_t)s.NF * PW);
+        std::memcpy(fixed.data(), gh, 2 * PW * 8);
+        std::memcpy(fixed.data() + 2 * PW, G, (size_t)s.mn * PW * 8);
+        std::memcpy(fixed.data() + (size_t)(2 + s.mn) * PW, H, (size_t)s.mn * PW * 8);
+        DevBuf dfixed;
+        rc = upload_points<C>(fixed.data(), s.NF, dfixed, nullptr);
+        if (rc) return rc;
+        bpp_verifier* v = new bpp_verifier();
+        v->ctx = ctx;
+        v->s = s;
+        const size_t entries = (size_t)s.NF * s.W * s.half;
+        v->table_bytes = entries * 2 * N * 4;
+        hipError_t e = v->table.alloc(v->table_bytes);
+        if (e != hipSuccess) {
+            delete v;
+            return fail(BPP_E_NOMEM, std::string("window table allocation failed: ") + hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(k_tbl_bases<C>, dim3(cdiv(s.NF, 64)), dim3(64), 0, nullptr, s, dfixed.u32(), v->table.u32());
+        // fill in slabs of generators so that one launch stays well below 2^31 blocks
+        const size_t per_f = (size_t)s.W * s.half;
+        const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 28) / per_f);
+        for (uint32_t f0 = 0; f0 < s.NF; f0 += slab) {
+            const uint32_t f1 = std::min<uint32_t>(s.NF, f0 + slab);
+            const size_t total = (size_t)(f1 - f0) * per_f;
+            hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 128)), dim3(128), 0, nullptr, s, v->table.u32(), f0, f1);
+        }
+        std::vector<uint32_t> ch;
+        default_challenges(s, ch);
+        e = v->challenges.alloc(ch.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(v->challenges.p, ch.data(), ch.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            delete v;
+            return fail(BPP_E_HIP, std::string("table build failed: ") + hipGetErrorString(e));
+        }
+        *out = v;
+        return BPP_OK;
+    }
+
+    static int run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                   const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
+                   uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st) {
+        const VerifyShape& s = v->s;
+        const WsLayout L = ws_layout(s, count);
+        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+        uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
+        uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
+        uint32_t* w_sc = d_out_scalars ? reinterpret_cast<uint32_t*>(d_out_scalars)
+                                       : reinterpret_cast<uint32_t*>(ws + L.scalars);
+        uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
+        uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
+        const unsigned bpp_ = blocks_per_proof(s, count);
+        const size_t npts = count * s.NV;
+        HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+        hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
+                           reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
+        const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
+        const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+        hipLaunchKernelGGL(k_verify_scalars<C>, dim3((unsigned)count), dim3(VS_BLOCK), 0, st, s,
+                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(bpp_, (unsigned)count), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
+                           s, w_sc, v->table.u32(), w_fp);
+        hipLaunchKernelGGL(k_var_msm<C>, dim3((unsigned)count), dim3(VAR_BLOCK), VAR_BLOCK * 3 * N * 4, st, s, w_sc,
+                           w_pts, w_vp);
+        hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_fp, bpp_, w_vp, w_bad, d_ok,
+                           reinterpret_cast<uint32_t*>(d_out_result), count);
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+};
+
+extern template struct VerifyImpl<Bls12381>;
+extern template struct VerifyImpl<Secp256k1>;
+
+}  // namespace bpp

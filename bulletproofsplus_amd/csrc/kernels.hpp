@@ -1,0 +1,546 @@
+// kernels.hpp -- HIP kernels of the Bulletproofs+ verify / MSM hot path for gfx950 (MI355X).
+//
+// Data layout in HBM (32-bit words, see ec.hpp for the point images):
+//   wire points      : canonical x | y | inf            (2N+2 words)   -- what the C ABI hands over
+//   "affm" points    : Montgomery x | y                 (2N words)     -- pk, proof points, tables
+//   jacobian partials: Montgomery X | Y | Z             (3N words)
+//   scalars          : canonical, 8 words (4 x u64)
+//   window table     : entry[(f * W + j) * half + (d - 1)] = d * 2^(c j) * F_f   (affm), d = 1..half,
+//                      half = 2^(c-1); F = [g, h, G_0.., H_0..] the verifier's fixed generators.
+//
+// Kernel inventory (each names the reference call site it serves; paths relative to /root/reference/src):
+//   k_points_from_wire   wire -> affm (+ on-curve check)
+//   k_scalar_mul         n independent Point * scalar          point/point.rs:69-85, publickey.rs:21-48
+//   k_msm_naive_partial  MulVec::calculate, one scalar-mul per thread + block reduce   mulvec.rs:20-33
+//   k_jac_reduce         sums jacobian partials of one MulVec -> wire point
+//   k_verify_scalars     all verifier scalars of one proof      wip.rs:330-382, range/mod.rs:417-477, :198-226,
+//                                                               wip.rs:254-295
+//   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables
+//                                                               range/mod.rs:480-503 / wip.rs:297-320
+//   k_var_msm            the 3+2k+m proof-dependent terms of the same MulVec
+//   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327
+//   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ec.hpp"
+
+namespace bpp {
+
+// launch geometry (threads per block) of the heavy kernels; the __launch_bounds__ below let the register
+// allocator use the whole 512-entry VGPR file at that occupancy instead of the 1024-thread default (128)
+constexpr unsigned MSM_BLOCK = 64;
+constexpr unsigned VS_BLOCK = 256;
+constexpr unsigned FIXED_BLOCK = 128;
+constexpr unsigned VAR_BLOCK = 64;
+
+// ---- small helpers -----------------------------------------------------------------------------------
+
+template <int NW>
+__device__ __forceinline__ void ld_words(const uint32_t* __restrict__ p, uint32_t* dst) {
+    static_assert(NW % 4 == 0, "16-byte granules");
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        uint4 v = q[i];
+        dst[4 * i] = v.x;
+        dst[4 * i + 1] = v.y;
+        dst[4 * i + 2] = v.z;
+        dst[4 * i + 3] = v.w;
+    }
+}
+template <int NW>
+__device__ __forceinline__ void st_words(uint32_t* __restrict__ p, const uint32_t* src) {
+    static_assert(NW % 4 == 0, "16-byte granules");
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) q[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+}
+
+template <class C>
+__device__ __forceinline__ Aff<C> aff_ldg(const uint32_t* __restrict__ p) {
+    constexpr int N = C::Fp::N;
+    uint32_t w[2 * N];
+    ld_words<2 * N>(p, w);
+    return aff_load<C>(w);
+}
+template <class C>
+__device__ __forceinline__ void aff_stg(uint32_t* __restrict__ p, const Aff<C>& a) {
+    constexpr int N = C::Fp::N;
+    uint32_t w[2 * N];
+    aff_store(a, w);
+    st_words<2 * N>(p, w);
+}
+template <class C>
+__device__ __forceinline__ Jac<C> jac_ldg(const uint32_t* __restrict__ p) {
+    constexpr int N = C::Fp::N;
+    uint32_t w[3 * N];
+    ld_words<3 * N>(p, w);
+    return jac_load<C>(w);
+}
+template <class C>
+__device__ __forceinline__ void jac_stg(uint32_t* __restrict__ p, const Jac<C>& a) {
+    constexpr int N = C::Fp::N;
+    uint32_t w[3 * N];
+    jac_store(a, w);
+    st_words<3 * N>(p, w);
+}
+
+// Sum of the jacobian accumulators of a thread block.  `lds` holds blockDim.x * 3N words.
+// On return thread 0 holds the block sum.  blockDim.x must be a power of two.
+template <class C>
+__device__ __forceinline__ Jac<C> block_reduce_jac(Jac<C> acc, uint32_t* lds) {
+    constexpr int N = C::Fp::N;
+    const int tid = threadIdx.x;
+    for (int half = blockDim.x >> 1; half >= 1; half >>= 1) {
+        if (tid >= half && tid < 2 * half) jac_store(acc, lds + (size_t)tid * 3 * N);
+        __syncthreads();
+        if (tid < half) acc = jac_add(acc, jac_load<C>(lds + (size_t)(tid + half) * 3 * N));
+        __syncthreads();
+    }
+    return acc;
+}
+
+// ---- wire <-> device images --------------------------------------------------------------------------
+
+// wire points -> affm.  per_group > 0: bad[i / per_group] is set when point i is invalid (coordinate
+// >= p or not on the curve); invalid points are replaced by infinity.
+template <class C>
+__global__ void __launch_bounds__(128) k_points_from_wire(const uint32_t* __restrict__ wire, uint32_t* __restrict__ affm,
+                                   uint32_t* __restrict__ bad, size_t n, uint32_t per_group) {
+    constexpr int N = C::Fp::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[2 * N + 2];
+#pragma unroll
+    for (int t = 0; t < 2 * N + 2; t++) w[t] = wire[i * (2 * N + 2) + t];
+    Aff<C> p;
+    const bool ok = aff_from_wire<C>(w, p);
+    if (!ok) {
+        p = aff_inf<C>();
+        if (bad) atomicOr(&bad[per_group ? i / per_group : 0], 1u);
+    }
+    aff_stg<C>(affm + i * 2 * N, p);
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restrict__ affm, uint32_t* __restrict__ wire, size_t n) {
+    constexpr int N = C::Fp::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<C> p = aff_ldg<C>(affm + i * 2 * N);
+    uint32_t w[2 * N + 2];
+    aff_to_wire(p, w);
+#pragma unroll
+    for (int t = 0; t < 2 * N + 2; t++) wire[i * (2 * N + 2) + t] = w[t];
+}
+
+// ---- scalar multiplication / naive MulVec ------------------------------------------------------------
+
+// out[i] = scalars[i] * points[i]  (affm in, affm out).  point_stride = 0 broadcasts points[0].
+template <class C>
+__global__ void __launch_bounds__(64) k_scalar_mul(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+                             size_t point_stride, uint32_t* __restrict__ out, size_t n) {
+    constexpr int N = C::Fp::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8];
+    ld_words<8>(scalars + i * 8, k);
+    Aff<C> p = aff_ldg<C>(points + i * point_stride);
+    Jac<C> r = aff_mul_words(p, k, 8);
+    aff_stg<C>(out + i * 2 * N, jac_to_aff(r));
+}
+
+// MulVec::calculate, data-parallel restatement of reference mulvec.rs:28-31: every thread performs the
+// scalar multiplications of its terms, a block reduces them; blockIdx.y selects the MulVec of a batch.
+// offsets[c] .. offsets[c+1] delimit MulVec c.  partials: [count][gridDim.x] jacobians.
+template <class C>
+__global__ void __launch_bounds__(MSM_BLOCK) k_msm_naive_partial(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+                                    const uint64_t* __restrict__ offsets, uint32_t* __restrict__ partials) {
+    constexpr int N = C::Fp::N;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const size_t c = blockIdx.y;
+    const size_t beg = offsets[c], end = offsets[c + 1];
+    Jac<C> acc = jac_inf<C>();
+    for (size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < end;
+         i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t k[8];
+        ld_words<8>(scalars + i * 8, k);
+        Aff<C> p = aff_ldg<C>(points + i * 2 * N);
+        acc = jac_add(acc, aff_mul_words(p, k, 8));
+    }
+    acc = block_reduce_jac<C>(acc, lds);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (c * gridDim.x + blockIdx.x) * 3 * N, acc);
+}
+
+// one thread per MulVec: sums its `per` jacobian partials, writes the wire point (affine, canonical)
+template <class C>
+__global__ void __launch_bounds__(64) k_jac_reduce(const uint32_t* __restrict__ partials, uint32_t per, uint32_t* __restrict__ wire_out,
+                             size_t count) {
+    constexpr int N = C::Fp::N;
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (c * per + t) * 3 * N));
+    uint32_t w[2 * N + 2];
+    aff_to_wire(jac_to_aff(acc), w);
+#pragma unroll
+    for (int t = 0; t < 2 * N + 2; t++) wire_out[c * (2 * N + 2) + t] = w[t];
+}
+
+// ---- verifier scalars --------------------------------------------------------------------------------
+
+struct VerifyShape {
+    uint32_t n, m, mn, k;      // bits per value, values, n*m, log2(mn)
+    uint32_t N;                // MulVec length 2mn + 2k + m + 5
+    uint32_t NF, NV;           // fixed terms 2mn + 2, proof-dependent terms 3 + 2k + m
+    uint32_t c, W, half;       // window bits, windows, 2^(c-1)
+    uint32_t bias[10];         // sum_j half * 2^(c j) as 32-bit words (signed-digit recoding bias)
+};
+
+// index of fixed generator f (0 = g, 1 = h, 2.. = G_i, 2+mn.. = H_i) in the MulVec
+__host__ __device__ __forceinline__ uint32_t fixed_term_index(const VerifyShape& s, uint32_t f) {
+    return f < 2 ? 3 + f : 5 + 2 * s.k + (f - 2);
+}
+// index, in the MulVec, of proof-dependent point v of a proof record [A, wip.A, wip.B, L.., R.., V..].
+// The head of the MulVec is [A, wip.A, wip.B] for m > 1 (range/mod.rs:492-494) but [wip.B, wip.A, A]
+// for m == 1 (wip.rs:309-311).
+__host__ __device__ __forceinline__ uint32_t var_term_index(const VerifyShape& s, uint32_t v) {
+    if (v < 3) return s.m == 1 ? 2 - v : v;
+    if (v < 3 + 2 * s.k) return 5 + (v - 3);
+    return 5 + 2 * s.k + 2 * s.mn + (v - 3 - 2 * s.k);
+}
+
+// util.rs:54-71 / :81-98 including the n == 1 quirk (returns 1 for both types)
+template <class P>
+__device__ Fe<P> sum_of_powers(const Fe<P>& x, uint32_t n, bool type2) {
+    if (n == 0) return Fe<P>::zero();
+    if (n == 1) return Fe<P>::one();
+    Fe<P> result = type2 ? fe_add(x, fe_sqr(x)) : fe_add(Fe<P>::one(), x);
+    Fe<P> factor = x;
+    uint32_t mm = n;
+    while (mm > 2) {
+        factor = fe_sqr(factor);
+        result = fe_add(result, fe_mul(factor, result));
+        mm >>= 1;
+    }
+    return result;
+}
+
+#define VS_MAXK 20
+#define VS_MAXM 64
+#define VS_MAXN 64
+
+// One block per proof.  Writes the N MulVec scalars of that proof (canonical, 8 words each) in the
+// reference's MulVec order:
+//   m > 1 (range/mod.rs:481-490): [1, e^-1, e^-2, g_exp, h_exp, e_i^2 (k), e_i^-2 (k), G_exp (mn), H_exp (mn), V_exp (m)]
+//   m = 1 (wip.rs:298-307)      : [1, e,    e^2,  g_exp, h_exp, e_i^2 e^2,  e_i^-2 e^2, G_exp (n),  H_exp (n),  V_exp (1)]
+// proof_scalars: [r', s', delta'] per proof; challenges: [y, z, e, e_1..e_k] (per proof when
+// ch_stride != 0, shared otherwise).  Inversions are done on device (Fermat), one lane each.
+template <class C>
+__global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, const uint32_t* __restrict__ proof_scalars,
+                                 const uint32_t* __restrict__ challenges, uint32_t ch_stride,
+                                 uint32_t* __restrict__ out) {
+    using P = typename C::Fr;
+    using F = Fe<P>;
+    __shared__ F sh_chsq[VS_MAXK], sh_chinv[VS_MAXK], sh_ypw[VS_MAXK + 1], sh_yipw[VS_MAXK + 1];
+    __shared__ F sh_pz[VS_MAXM], sh_p2[VS_MAXN];
+    __shared__ F sh_allinv, sh_yinv, sh_einv, sh_cG, sh_kG, sh_kH, sh_cH, sh_z;
+    const uint32_t tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const uint32_t* ch = challenges + (size_t)ch_stride * b;
+    uint32_t* o = out + b * (size_t)s.N * 8;
+    const uint32_t k = s.k, mn = s.mn;
+
+    // phase A: inversions, one lane each (e_1..e_k, y, e) ; 2^t as field elements
+    if (tid < k + 2) {
+        uint32_t w[8];
+        const uint32_t src = tid < k ? 3 + tid : (tid == k ? 0 : 2);
+        ld_words<8>(ch + src * 8, w);
+        F x = fe_from_canonical<P>(w);
+        F xi = fe_inv(x);
+        if (tid < k) {
+            sh_chsq[tid] = fe_sqr(x);
+            sh_chinv[tid] = xi;
+        } else if (tid == k) {
+            sh_yinv = xi;
+        } else {
+            sh_einv = xi;
+        }
+    } else if (tid >= 64 && tid < 64 + s.n && tid - 64 < VS_MAXN) {
+        const uint32_t t = tid - 64;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        w[t >> 5] = 1u << (t & 31);
+        sh_p2[t] = fe_from_canonical<P>(w);
+    }
+    __syncthreads();
+
+    // phase B: per-proof constants (thread 0) ; power tables (thread 64, a different wave)
+    if (tid == 0) {
+        uint32_t w[8];
+        ld_words<8>(ch + 0, w);
+        F y = fe_from_canonical<P>(w);
+        ld_words<8>(ch + 8, w);
+        F z = fe_from_canonical<P>(w);
+        ld_words<8>(ch + 16, w);
+        F e = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24, w);
+        F rp = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24 + 8, w);
+        F sp = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24 + 16, w);
+        F dp = fe_from_canonical<P>(w);
+        F allinv = F::one();
+        for (uint32_t j = 0; j < k; j++) allinv = fe_mul(allinv, sh_chinv[j]);  // batch_invert's product
+        sh_allinv = allinv;
+        sh_z = z;
+        const F einv = sh_einv;
+        const F zsq = fe_sqr(z);
+        F head1, head2, g_exp, h_exp, lr_mul;
+        if (s.m == 1) {
+            // range/mod.rs:198-226 + wip.rs:254-295
+            const F esq = fe_sqr(e);
+            head1 = e;
+            head2 = esq;
+            sh_cG = fe_mul(fe_neg(z), esq);
+            sh_kG = fe_mul(fe_mul(rp, e), y);
+            sh_kH = fe_mul(sp, e);
+            sh_cH = esq;
+            const F y_n1 = fe_pow_u64(y, (uint64_t)s.n + 1);
+            F gc = F::zero();  // sum_{i<n} y^{i+1}
+            {
+                F cur = y;
+                for (uint32_t i = 0; i < s.n; i++) {
+                    gc = fe_add(gc, cur);
+                    cur = fe_mul(cur, y);
+                }
+            }
+            gc = fe_mul(gc, fe_sub(z, zsq));
+            F two = fe_from_u32<P>(2);
+            F t = fe_sub(fe_pow_u64(two, s.n), F::one());
+            gc = fe_sub(gc, fe_mul(fe_mul(t, y_n1), z));
+            g_exp = fe_add(fe_mul(fe_mul(fe_neg(rp), y), sp), fe_mul(gc, esq));
+            h_exp = fe_neg(dp);
+            lr_mul = esq;
+            sh_pz[0] = fe_mul(y_n1, esq);  // V_exp
+        } else {
+            // range/mod.rs:417-477
+            const F einv2 = fe_sqr(einv);  // == (e^2)^-1
+            head1 = einv;
+            head2 = einv2;
+            sh_cG = fe_neg(z);
+            sh_kG = fe_mul(fe_mul(rp, einv), y);
+            sh_kH = fe_mul(sp, einv);
+            sh_cH = F::one();
+            const F y_mn1 = fe_pow_u64(y, (uint64_t)mn + 1);
+            const F sum_y = sum_of_powers<P>(y, mn, true);
+            const F sum_2 = sum_of_powers<P>(fe_from_u32<P>(2), s.n, false);
+            const F sum_z = sum_of_powers<P>(zsq, s.m, true);
+            F t1 = fe_mul(fe_mul(fe_mul(fe_neg(rp), sp), y), einv2);
+            F t2 = fe_sub(fe_mul(sum_y, fe_sub(z, zsq)), fe_mul(fe_mul(fe_mul(y_mn1, z), sum_2), sum_z));
+            g_exp = fe_add(t1, t2);
+            h_exp = fe_mul(fe_neg(dp), einv2);
+            lr_mul = F::one();
+            F cur = zsq;
+            for (uint32_t j = 0; j < s.m; j++) {  // power_of_z and V_exp
+                sh_pz[j] = cur;
+                uint32_t wv[8];
+                fe_to_canonical(fe_mul(cur, y_mn1), wv);
+                st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn + j) * 8, wv);
+                cur = fe_mul(cur, zsq);
+            }
+        }
+        uint32_t wv[8];
+        fe_to_canonical(F::one(), wv);
+        st_words<8>(o + 0, wv);
+        fe_to_canonical(head1, wv);
+        st_words<8>(o + 8, wv);
+        fe_to_canonical(head2, wv);
+        st_words<8>(o + 16, wv);
+        fe_to_canonical(g_exp, wv);
+        st_words<8>(o + 24, wv);
+        fe_to_canonical(h_exp, wv);
+        st_words<8>(o + 32, wv);
+        for (uint32_t j = 0; j < k; j++) {
+            fe_to_canonical(fe_mul(sh_chsq[j], lr_mul), wv);
+            st_words<8>(o + (size_t)(5 + j) * 8, wv);
+            fe_to_canonical(fe_mul(fe_sqr(sh_chinv[j]), lr_mul), wv);
+            st_words<8>(o + (size_t)(5 + k + j) * 8, wv);
+        }
+        if (s.m == 1) {
+            fe_to_canonical(sh_pz[0], wv);
+            st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn) * 8, wv);
+        }
+    } else if (tid == 64) {
+        uint32_t w[8];
+        ld_words<8>(ch + 0, w);
+        F y = fe_from_canonical<P>(w);
+        F yi = sh_yinv;
+        for (uint32_t bnum = 0; bnum <= k; bnum++) {  // y^(2^b), y^-(2^b)
+            sh_ypw[bnum] = y;
+            sh_yipw[bnum] = yi;
+            y = fe_sqr(y);
+            yi = fe_sqr(yi);
+        }
+    }
+    __syncthreads();
+
+    // phase C: G_exp[i], H_exp[i]
+    const F allinv = sh_allinv, cG = sh_cG, kG = sh_kG, kH = sh_kH, cH = sh_cH, z = sh_z;
+    for (uint32_t i = tid; i < mn; i += blockDim.x) {
+        // s_vec[i] = allinv * prod_{bit b of i set} e^2_{k-1-b}   (wip.rs:372-380 unrolled);
+        // s_vec[mn-1-i] takes the complementary bits
+        F sp_i = allinv, sr_i = allinv;
+        for (uint32_t bnum = 0; bnum < k; bnum++) {
+            const F u = sh_chsq[k - 1 - bnum];
+            if ((i >> bnum) & 1u) sp_i = fe_mul(sp_i, u);
+            else sr_i = fe_mul(sr_i, u);
+        }
+        F yip = F::one(), yp = F::one();  // y^-(i+1), y^(mn-i)
+        const uint32_t e1 = i + 1, e2 = mn - i;
+        for (uint32_t bnum = 0; bnum <= k; bnum++) {
+            if ((e1 >> bnum) & 1u) yip = fe_mul(yip, sh_yipw[bnum]);
+            if ((e2 >> bnum) & 1u) yp = fe_mul(yp, sh_ypw[bnum]);
+        }
+        // G_exp = cG - s_i * y^-(i+1) * kG        (range/mod.rs:456-459 ; wip.rs:273-280)
+        F ge = fe_sub(cG, fe_mul(fe_mul(sp_i, yip), kG));
+        // H_exp = -kH * s_{mn-1-i} + (d_i * y^(mn-i) + z) * cH     (range/mod.rs:461-465 ; wip.rs:282-286)
+        F d = sh_p2[i % s.n];
+        if (s.m != 1) d = fe_mul(d, sh_pz[i / s.n]);
+        F he = fe_add(fe_mul(d, yp), z);
+        if (s.m == 1) he = fe_mul(he, cH);
+        he = fe_sub(he, fe_mul(kH, sr_i));
+        uint32_t wv[8];
+        fe_to_canonical(ge, wv);
+        st_words<8>(o + (size_t)(5 + 2 * k + i) * 8, wv);
+        fe_to_canonical(he, wv);
+        st_words<8>(o + (size_t)(5 + 2 * k + mn + i) * 8, wv);
+    }
+}
+
+// ---- window tables -------------------------------------------------------------------------------------
+
+// thread f: base_{f,j} = 2^(c j) * F_f for every window j, written as entry d = 1
+template <class C>
+__global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t* __restrict__ fixed_pts, uint32_t* __restrict__ table) {
+    constexpr int N = C::Fp::N;
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= s.NF) return;
+    Aff<C> p = aff_ldg<C>(fixed_pts + (size_t)f * 2 * N);
+    for (uint32_t j = 0; j < s.W; j++) {
+        aff_stg<C>(table + ((size_t)(f * s.W + j) * s.half) * 2 * N, p);
+        if (j + 1 < s.W) {
+            Jac<C> q = jac_from_aff(p);
+            for (uint32_t t = 0; t < s.c; t++) q = jac_dbl(q);
+            p = jac_to_aff(q);
+        }
+    }
+}
+
+// one thread per entry: entry d = d * base (d = 2..half), affine
+template <class C>
+__global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t f_begin, uint32_t f_end) {
+    constexpr int N = C::Fp::N;
+    const size_t per_f = (size_t)s.W * s.half;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(f_end - f_begin) * per_f;
+    if (idx >= total) return;
+    const size_t e = (size_t)f_begin * per_f + idx;
+    const uint32_t d = (uint32_t)(e % s.half) + 1;
+    if (d == 1) return;
+    const size_t base_e = e - (d - 1);
+    Aff<C> base = aff_ldg<C>(table + base_e * 2 * N);
+    uint32_t kw[1] = {d};
+    Jac<C> r = aff_mul_words(base, kw, 1);
+    aff_stg<C>(table + e * 2 * N, jac_to_aff(r));
+}
+
+// ---- the verification MulVec ---------------------------------------------------------------------------
+
+// Fixed-generator part: for proof b = blockIdx.y, sum_f scalar_f * F_f through the window tables.
+// scalar + bias -> W unsigned windows -> signed digits in [-half, half) -> one table gather and one mixed
+// addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
+// that.  partials: [count][gridDim.x] jacobians.
+template <class C>
+__global__ void __launch_bounds__(FIXED_BLOCK) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
+                            const uint32_t* __restrict__ table, uint32_t* __restrict__ partials) {
+    constexpr int N = C::Fp::N;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const size_t b = blockIdx.y;
+    const uint32_t* sc = scalars + b * (size_t)s.N * 8;
+    const uint32_t mask = (1u << s.c) - 1u;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < s.NF; f += gridDim.x * blockDim.x) {
+        uint32_t w[10];
+        ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, w);
+        w[8] = 0;
+        w[9] = 0;
+        // + bias K = sum_j half * 2^(c j): window j of (scalar + K) minus half is the signed digit
+        {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int t = 0; t < 10; t++) {
+                uint64_t x = (uint64_t)w[t] + s.bias[t] + carry;
+                w[t] = (uint32_t)x;
+                carry = (uint32_t)(x >> 32);
+            }
+        }
+        const uint32_t* tf = table + ((size_t)f * s.W * s.half) * 2 * N;
+        for (uint32_t j = 0; j < s.W; j++) {
+            const int32_t dg = (int32_t)(w[0] & mask) - (int32_t)s.half;
+            // shift the 320-bit value right by c
+#pragma unroll
+            for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
+            w[9] >>= s.c;
+            if (dg != 0) {
+                const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
+                Aff<C> q = aff_ldg<C>(tf + ((size_t)j * s.half + (mag - 1)) * 2 * N);
+                if (dg < 0) q.y = fe_neg(q.y);
+                acc = jac_madd(acc, q);
+            }
+        }
+    }
+    acc = block_reduce_jac<C>(acc, lds);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (b * gridDim.x + blockIdx.x) * 3 * N, acc);
+}
+
+// Proof-dependent part: the 3 + 2k + m points carried by the proof / commitments, one scalar
+// multiplication per lane, one block per proof.  partial: [count] jacobians.
+template <class C>
+__global__ void __launch_bounds__(VAR_BLOCK) k_var_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
+                          const uint32_t* __restrict__ proof_pts, uint32_t* __restrict__ partial) {
+    constexpr int N = C::Fp::N;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const size_t b = blockIdx.x;
+    const uint32_t* sc = scalars + b * (size_t)s.N * 8;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t v = threadIdx.x; v < s.NV; v += blockDim.x) {
+        uint32_t k[8];
+        ld_words<8>(sc + (size_t)var_term_index(s, v) * 8, k);
+        Aff<C> p = aff_ldg<C>(proof_pts + (b * s.NV + v) * 2 * N);
+        acc = jac_add(acc, aff_mul_words(p, k, 8));
+    }
+    acc = block_reduce_jac<C>(acc, lds);
+    if (threadIdx.x == 0) jac_stg<C>(partial + b * 3 * N, acc);
+}
+
+// expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError
+// (range/mod.rs:503-509, wip.rs:320-327).  A proof with an invalid point is rejected.
+template <class C>
+__global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fixed_partials, uint32_t per,
+                           const uint32_t* __restrict__ var_partial, const uint32_t* __restrict__ bad,
+                           uint32_t* __restrict__ ok, uint32_t* __restrict__ wire_result, size_t count) {
+    constexpr int N = C::Fp::N;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    Jac<C> acc = jac_ldg<C>(var_partial + b * 3 * N);
+    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * 3 * N));
+    ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
+    if (wire_result) {
+        uint32_t w[2 * N + 2];
+        aff_to_wire(jac_to_aff(acc), w);
+#pragma unroll
+        for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
+    }
+}
+
+}  // namespace bpp

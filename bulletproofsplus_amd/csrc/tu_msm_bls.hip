@@ -1,0 +1,5 @@
+// explicit instantiation: MsmImpl<Bls12381> (its kernels are compiled in this translation unit only)
+#include "impl_msm.hpp"
+namespace bpp {
+template struct MsmImpl<Bls12381>;
+}

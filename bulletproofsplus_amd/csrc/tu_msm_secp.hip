@@ -1,0 +1,5 @@
+// explicit instantiation: MsmImpl<Secp256k1> (its kernels are compiled in this translation unit only)
+#include "impl_msm.hpp"
+namespace bpp {
+template struct MsmImpl<Secp256k1>;
+}

@@ -1,0 +1,142 @@
+/*
+ * bpp_amd.h -- C ABI of the MI355X-native Bulletproofs+ engine (libbpp_amd.so).
+ *
+ * This is the drop-in boundary for the reference crate's hot path (gogoex/BulletProofsPlus): every
+ * entry point below names the reference interface it replaces (paths relative to /root/reference).
+ * The reference has no FFI of its own; its only ABI crossing is Rust -> libmcl inside mcl_rust.
+ * Here the crossing moves up to the MulVec / RangeProof level: host -> extern "C" -> HIP.
+ * INTEGRATION.md shows the Rust `extern "C"` block and the replacement bodies of
+ * `MulVec::calculate`, `RangeProof::{prove,verify}`, `PublicKey::new`, `RangeProver::commit`.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every buffer; nothing borrowed outlives a call.
+ *   - return value: 0 = Ok(()), 1 = Err(ProofError::VerificationError)
+ *     (reference src/errors.rs:14-50; the only variant the path constructs, range/mod.rs:508,
+ *     weighted_inner_product_proof.rs:326,336), negative = usage / runtime error (BPP_E_*), where the
+ *     reference would panic (mulvec.rs:23-25, range/mod.rs:90-91,252-253, wip.rs:60-67).
+ *     Nothing unwinds, nothing is printed.
+ *   - scalar: 4 x uint64_t little-endian limbs, canonical (non-Montgomery) value; values >= r are
+ *     reduced mod r on entry.
+ *   - point : (2*L + 1) x uint64_t = affine x (L limbs LE) | y (L limbs LE) | infinity flag (0/1),
+ *     canonical coordinates; L = 6 for BLS12-381 G1, 4 for secp256k1 (bpp_point_words()).
+ *   - there is no CPU fallback: every call runs HIP kernels on the context's device and fails with
+ *     BPP_E_HIP if the device is unusable.
+ *   - a context is bound to one device and one thread at a time; contexts are independent.
+ */
+#ifndef BPP_AMD_H
+#define BPP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* curve ids.  BLS12-381 G1 is what the reference's range proof is wired to (src/range/mod.rs:10-15);
+ * secp256k1 is its second, in-tree backend (src/secp256k1/building_block/). */
+#define BPP_BLS12_381_G1 0
+#define BPP_SECP256K1 1
+
+#define BPP_OK 0
+#define BPP_VERIFICATION_ERROR 1
+#define BPP_E_ARG (-1)      /* bad argument (null pointer, unknown curve, n*m not a power of two...) */
+#define BPP_E_HIP (-2)      /* HIP runtime error; bpp_last_error() has the text */
+#define BPP_E_LENGTH (-3)   /* "mulvec: lengths of scalars and points must match" and friends */
+#define BPP_E_POINT (-4)    /* a point is not on the curve / coordinate >= p */
+#define BPP_E_NOMEM (-5)
+
+typedef struct bpp_ctx bpp_ctx;
+typedef struct bpp_verifier bpp_verifier;
+
+/* Arith::init (src/bls12_381/building_block/arith.rs:6-19): one-time library/device initialisation.
+ * `device` is the HIP device ordinal. */
+int bpp_init(int curve_id, int device, bpp_ctx **out_ctx);
+void bpp_destroy(bpp_ctx *ctx);
+const char *bpp_last_error(void);
+
+/* words (uint64_t) per wire point for a curve: 2*L + 1 */
+int bpp_point_words(int curve_id);
+
+/* MulVec::calculate (src/bls12_381/building_block/mulvec.rs:20-33; secp256k1 twin
+ * src/secp256k1/building_block/secp256k1/util.rs:22-36): out = sum_i scalars[i] * points[i].
+ * n == 0 gives the point at infinity (Point::zero()).  Host pointers. */
+int bpp_msm(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out);
+
+/* `count` independent MulVecs in one launch: MulVec c has lens[c] terms starting at offset
+ * sum(lens[0..c)).  out: count points.  (The fold of src/weighted_inner_product_proof.rs:151-163 is
+ * 2 n' MulVecs of length 2.)  Host pointers. */
+int bpp_msm_batch(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, const uint32_t *lens,
+                  size_t count, uint64_t *out);
+
+/* Point * PrimeFieldElem for n independent pairs (src/bls12_381/building_block/point/point.rs:69-85).
+ * Host pointers. */
+int bpp_scalar_mul_batch(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_t n,
+                         uint64_t *out);
+
+/* PublicKey::new(length) (src/publickey.rs:21-48): g = base point, h = 2g, G_i = 3(i+1) g,
+ * H_i = 5(i+1) g.  out_gh: 2 points [g, h]; out_G, out_H: `length` points each. */
+int bpp_pk_new(bpp_ctx *ctx, size_t length, uint64_t *out_gh, uint64_t *out_G, uint64_t *out_H);
+
+/* RangeProver::commit / PublicKey::commitment (src/range/prover.rs:28-42, src/publickey.rs:50-52):
+ * out = g * new(v as i32) + h * gamma.  The `v as i32` truncation of prover.rs:37 is kept. */
+int bpp_commit(bpp_ctx *ctx, const uint64_t *gh, uint64_t v, const uint64_t *gamma, uint64_t *out);
+
+/* RangeProof::prove (src/range/mod.rs:31-55 -> prove_single :80-187 / prove_multiple :240-403, and
+ * WeightedInnerProductProof::prove, src/weighted_inner_product_proof.rs:36-227).
+ * pk = (gh, G, H) with n*m generators each; v[m], gamma[m] (scalars), V[m] commitments.
+ * out_points : 3 + 2k points  [A, wip.A, wip.B, L_0..L_{k-1}, R_0..R_{k-1}],  k = log2(n*m)
+ * out_scalars: 3 scalars      [r', s', delta'] */
+int bpp_range_prove(bpp_ctx *ctx, const uint64_t *gh, const uint64_t *G, const uint64_t *H, size_t n,
+                    size_t m, const uint64_t *v, const uint64_t *gamma, const uint64_t *V,
+                    uint64_t *out_points, uint64_t *out_scalars);
+
+/* RangeProof::verify (src/range/mod.rs:57-78 -> verify_single :189-238 + wip verify
+ * src/weighted_inner_product_proof.rs:238-328, or verify_multiple :405-510).
+ * proof_points as written by bpp_range_prove with k rounds.  Returns 0 / 1 / negative. */
+int bpp_range_verify(bpp_ctx *ctx, const uint64_t *gh, const uint64_t *G, const uint64_t *H, size_t n,
+                     size_t m, const uint64_t *proof_points, size_t k, const uint64_t *proof_scalars,
+                     const uint64_t *V);
+
+/* ---- batch verifier: the north-star path -----------------------------------------------------
+ * A verifier holds the public key in HBM together with the fixed-base window tables built from it
+ * (see DESIGN.md), for one (n, m).  Proof batches are DEVICE buffers (e.g. torch CUDA tensors'
+ * data_ptr()), so a step of the hot path touches no host memory:
+ *   d_points  : count x (3 + 2k + m) wire points   [A, wip.A, wip.B, L_0.., R_0.., V_0..V_{m-1}]
+ *   d_scalars : count x 3 scalars                  [r', s', delta']
+ *   d_ok      : count x uint32_t                   0 = Ok(()), 1 = Err(VerificationError)
+ * The reference has no batch API (src/lib.rs:11-13); each entry of d_ok is exactly the verdict
+ * RangeProof::verify would return for that proof. */
+int bpp_verifier_create(bpp_ctx *ctx, const uint64_t *gh, const uint64_t *G, const uint64_t *H, size_t n,
+                        size_t m, int window_bits, bpp_verifier **out);
+void bpp_verifier_destroy(bpp_verifier *v);
+/* bytes of device workspace bpp_verifier_run needs for `count` proofs */
+size_t bpp_verifier_workspace_bytes(const bpp_verifier *v, size_t count);
+/* number of MulVec terms per proof, N = 2mn + 2k + m + 5 */
+size_t bpp_verifier_msm_len(const bpp_verifier *v);
+/* bytes of HBM held by the window tables */
+size_t bpp_verifier_table_bytes(const bpp_verifier *v);
+
+/* One pass of the hot path over a resident batch, asynchronous on `stream` (a hipStream_t; NULL =
+ * default stream).  d_challenges is NULL (the reference's hard-coded "transcript") or
+ * count x (3 + k) scalars [y, z, e, e_1..e_k] per proof.
+ * Optional debug / parity outputs (NULL to skip):
+ *   d_out_scalars: count x N scalars -- the MulVec scalars in the reference's MulVec order
+ *                  (range/mod.rs:481-490 for m > 1, wip.rs:298-307 for m == 1)
+ *   d_out_result : count x wire point -- the MulVec result ("expected", range/mod.rs:503) */
+int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                     const uint64_t *d_challenges, uint32_t *d_ok, void *d_workspace,
+                     size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
+                     void *stream);
+
+/* Host-pointer convenience over bpp_verifier_run (allocates, copies, synchronises). */
+int bpp_range_verify_batch(bpp_verifier *v, const uint64_t *points, const uint64_t *scalars, size_t count,
+                           uint32_t *out_ok);
+
+/* name of the kernel that dominates bpp_verifier_run (for profilers) and its launch geometry */
+const char *bpp_verifier_dominant_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPP_AMD_H */

