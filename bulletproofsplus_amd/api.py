@@ -342,6 +342,27 @@ class BatchVerifier:
                                           stream or None), "bpp_verifier_run")
 
 
+STAGES = ("from_wire", "verify_scalars", "fixed_msm", "var_msm", "finalize")
+
+
+def _verifier_set_profiling(self, on: bool):
+    check(_lib.lib().bpp_verifier_set_profiling(self.handle, 1 if on else 0), "bpp_verifier_set_profiling")
+
+
+def _verifier_profile(self):
+    """-> ({stage: mean ms}, passes, blocks_per_proof of k_fixed_msm), HIP events on the launch stream"""
+    ms = (ctypes.c_float * 5)()
+    passes = ctypes.c_size_t()
+    bpp_ = ctypes.c_uint()
+    check(_lib.lib().bpp_verifier_profile(self.handle, ms, ctypes.byref(passes), ctypes.byref(bpp_)),
+          "bpp_verifier_profile")
+    return {k: float(ms[i]) for i, k in enumerate(STAGES)}, passes.value, bpp_.value
+
+
+BatchVerifier.set_profiling = _verifier_set_profiling
+BatchVerifier.profile = _verifier_profile
+
+
 def proof_record(proof: RangeProof, commitment_vec) -> np.ndarray:
     """[A, wip.A, wip.B, L.., R.., V..] -- the per-proof point record of the batch verifier."""
     return np.concatenate([proof.points_wire(), np.asarray(commitment_vec, dtype=np.uint64)])

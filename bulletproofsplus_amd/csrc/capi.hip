@@ -128,6 +128,39 @@ extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const
     });
 }
 
+extern "C" int bpp_verifier_set_profiling(bpp_verifier* v, int on) {
+    if (!v) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    if (on && v->events.empty()) {
+        v->events.resize((size_t)BPP_PROFILE_SLOTS * (BPP_NUM_STAGES + 1));
+        for (hipEvent_t& e : v->events) HIPCHK(hipEventCreate(&e));
+    }
+    v->profiling = on != 0;
+    v->passes_recorded = 0;
+    return BPP_OK;
+}
+
+extern "C" int bpp_verifier_profile(bpp_verifier* v, float* out_stage_ms, size_t* out_passes,
+                                    unsigned* out_blocks_per_proof) {
+    if (!v || !out_stage_ms) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    const size_t np = std::min<size_t>(v->passes_recorded, BPP_PROFILE_SLOTS);
+    for (int t = 0; t < BPP_NUM_STAGES; t++) out_stage_ms[t] = 0.f;
+    for (size_t p = 0; p < np; p++) {
+        hipEvent_t* ev = v->events.data() + p * (BPP_NUM_STAGES + 1);
+        HIPCHK(hipEventSynchronize(ev[BPP_NUM_STAGES]));
+        for (int t = 0; t < BPP_NUM_STAGES; t++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[t], ev[t + 1]));
+            out_stage_ms[t] += ms;
+        }
+    }
+    for (int t = 0; t < BPP_NUM_STAGES; t++) out_stage_ms[t] = np ? out_stage_ms[t] / (float)np : 0.f;
+    if (out_passes) *out_passes = np;
+    if (out_blocks_per_proof) *out_blocks_per_proof = v->last_blocks_per_proof;
+    return BPP_OK;
+}
+
 extern "C" int bpp_range_verify_batch(bpp_verifier* v, const uint64_t* points, const uint64_t* scalars, size_t count,
                                       uint32_t* out_ok) {
     if (!v || !points || !scalars || !out_ok) return fail(BPP_E_ARG, "null argument");

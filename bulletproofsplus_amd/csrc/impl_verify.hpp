@@ -3,12 +3,25 @@
 #pragma once
 #include "host_util.hpp"
 
+// stages of one pass, in launch order (bpp_verifier_profile reports one duration per stage)
+enum { BPP_STAGE_FROM_WIRE = 0, BPP_STAGE_SCALARS, BPP_STAGE_FIXED_MSM, BPP_STAGE_VAR_MSM, BPP_STAGE_FINALIZE,
+       BPP_NUM_STAGES };
+constexpr int BPP_PROFILE_SLOTS = 64;  // passes remembered by the event ring
+
 struct bpp_verifier {
     bpp_ctx ctx;
     bpp::VerifyShape s;
     bpp::DevBuf table;       // window tables
     bpp::DevBuf challenges;  // default challenges
     size_t table_bytes = 0;
+    // optional per-stage HIP-event timing (recorded on the caller's stream)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x (BPP_NUM_STAGES + 1)
+    size_t passes_recorded = 0;
+    unsigned last_blocks_per_proof = 0;
+    ~bpp_verifier() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
 };
 
 namespace bpp {
@@ -109,19 +122,31 @@ struct VerifyImpl {
         uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
         const unsigned bpp_ = blocks_per_proof(s, count);
         const size_t npts = count * s.NV;
+        hipEvent_t* ev = nullptr;
+        if (v->profiling) {
+            ev = v->events.data() + (v->passes_recorded % BPP_PROFILE_SLOTS) * (BPP_NUM_STAGES + 1);
+            v->passes_recorded++;
+        }
+        v->last_blocks_per_proof = bpp_;
         HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+        if (ev) HIPCHK(hipEventRecord(ev[0], st));
         hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
                            reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
         const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
         const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+        if (ev) HIPCHK(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3((unsigned)count), dim3(VS_BLOCK), 0, st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc);
+        if (ev) HIPCHK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3(bpp_, (unsigned)count), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
                            s, w_sc, v->table.u32(), w_fp);
+        if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_var_msm<C>, dim3((unsigned)count), dim3(VAR_BLOCK), VAR_BLOCK * 3 * N * 4, st, s, w_sc,
                            w_pts, w_vp);
+        if (ev) HIPCHK(hipEventRecord(ev[4], st));
         hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_fp, bpp_, w_vp, w_bad, d_ok,
                            reinterpret_cast<uint32_t*>(d_out_result), count);
+        if (ev) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }

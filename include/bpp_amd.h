@@ -129,6 +129,13 @@ int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *
                      size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
                      void *stream);
 
+/* Per-stage timing with HIP events recorded on the caller's stream around each kernel of a pass
+ * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant], 3 proof-point MSM,
+ * 4 finalize).  bpp_verifier_profile averages over the passes recorded since profiling was switched on
+ * (at most 64): out_stage_ms[5]. */
+int bpp_verifier_set_profiling(bpp_verifier *v, int on);
+int bpp_verifier_profile(bpp_verifier *v, float *out_stage_ms, size_t *out_passes, unsigned *out_blocks_per_proof);
+
 /* Host-pointer convenience over bpp_verifier_run (allocates, copies, synchronises). */
 int bpp_range_verify_batch(bpp_verifier *v, const uint64_t *points, const uint64_t *scalars, size_t count,
                            uint32_t *out_ok);
