@@ -82,12 +82,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
+    ap.add_argument("--batch", type=int, default=8192, help="proofs per GPU per step")
     ap.add_argument("--distinct", type=int, default=32, help="distinct proofs generated per GPU (tiled to --batch)")
     ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "secp256k1"])
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--m", type=int, default=16)
-    ap.add_argument("--window", type=int, default=13)
+    ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(8, cores); -1 disables the CPU leg")
     ap.add_argument("--cpu-per-thread", type=int, default=2)
     args = ap.parse_args()

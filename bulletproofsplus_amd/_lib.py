@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbpp_amd.so")
+# BPP_AMD_LIB selects an alternative build of the same library (A/B experiments); default is the in-tree one
+LIB_PATH = os.environ.get("BPP_AMD_LIB") or os.path.join(_HERE, "libbpp_amd.so")
 
 BLS12_381_G1 = 0
 SECP256K1 = 1

@@ -193,7 +193,7 @@ extern "C" int bpp_debug_field_op(bpp_ctx* ctx, int field, int op, const uint32_
         return MsmImpl<decltype(cv)>::debug_field_op(field, op, a, b, n, out);
     });
 }
-// op: 0 add, 1 madd, 2 dbl(a), 3 madd(2a, b), 4 add(2a, 2b); wire points, host pointers
+// op: 0 add, 1 madd, 2 dbl(a), 3 madd(2a, b), 4 add(2a, 2b), 5 xyzz: inf + a + b + a; wire points, host pointers
 extern "C" int bpp_debug_point_op(bpp_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t n,
                                   uint64_t* out) {
     if (!ctx || !a || !b || !out) return fail(BPP_E_ARG, "null argument");

@@ -218,6 +218,83 @@ BPP_HD Aff<C> jac_to_aff(const Jac<C>& p) {
     return r;
 }
 
+// ---- XYZZ accumulator (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; ZZ = 0 encodes infinity) ----------------------
+// Used where a running sum only ever receives affine points (the fixed-generator MSM): the mixed addition
+// costs 8M + 2S (madd-2008-s) against 7M + 4S for jacobian madd-2007-bl, with about half the add/sub work.
+template <class C>
+struct Xyzz {
+    Fe<typename C::Fp> X, Y, ZZ, ZZZ;
+    BPP_HD bool is_inf() const { return ZZ.is_zero(); }
+};
+template <class C>
+BPP_HD Xyzz<C> xyzz_inf() {
+    Xyzz<C> r;
+    r.X = Fe<typename C::Fp>::one();
+    r.Y = Fe<typename C::Fp>::one();
+    r.ZZ = Fe<typename C::Fp>::zero();
+    r.ZZZ = Fe<typename C::Fp>::zero();
+    return r;
+}
+// 2 * (affine q), mdbl-2008-s-1 with a = 0
+template <class C>
+BPP_HD Xyzz<C> xyzz_dbl_aff(const Aff<C>& q) {
+    using F = Fe<typename C::Fp>;
+    if (q.is_inf()) return xyzz_inf<C>();
+    F U = fe_dbl(q.y);
+    F V = fe_sqr(U);
+    F W = fe_mul(U, V);
+    F S = fe_mul(q.x, V);
+    F xx = fe_sqr(q.x);
+    F M = fe_add(fe_dbl(xx), xx);
+    Xyzz<C> r;
+    r.X = fe_sub(fe_sqr(M), fe_dbl(S));
+    r.Y = fe_sub(fe_mul(M, fe_sub(S, r.X)), fe_mul(W, q.y));
+    r.ZZ = V;
+    r.ZZZ = W;
+    return r;
+}
+// acc + affine q, complete for the reference's cases (inf, equal, opposite)
+template <class C>
+BPP_HD Xyzz<C> xyzz_madd(const Xyzz<C>& p, const Aff<C>& q) {
+    using F = Fe<typename C::Fp>;
+    if (q.is_inf()) return p;
+    if (p.is_inf()) {
+        Xyzz<C> r;
+        r.X = q.x;
+        r.Y = q.y;
+        r.ZZ = F::one();
+        r.ZZZ = F::one();
+        return r;
+    }
+    F U2 = fe_mul(q.x, p.ZZ);
+    F S2 = fe_mul(q.y, p.ZZZ);
+    F Pp = fe_sub(U2, p.X);
+    F R = fe_sub(S2, p.Y);
+    if (Pp.is_zero()) {
+        if (R.is_zero()) return xyzz_dbl_aff(q);
+        return xyzz_inf<C>();
+    }
+    F PP = fe_sqr(Pp);
+    F PPP = fe_mul(Pp, PP);
+    F Q = fe_mul(p.X, PP);
+    Xyzz<C> r;
+    r.X = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    r.Y = fe_sub(fe_mul(R, fe_sub(Q, r.X)), fe_mul(p.Y, PPP));
+    r.ZZ = fe_mul(p.ZZ, PP);
+    r.ZZZ = fe_mul(p.ZZZ, PPP);
+    return r;
+}
+// jacobian image with Z = ZZ: (X * ZZ, Y * ZZZ, ZZ)
+template <class C>
+BPP_HD Jac<C> xyzz_to_jac(const Xyzz<C>& p) {
+    if (p.is_inf()) return jac_inf<C>();
+    Jac<C> r;
+    r.X = fe_mul(p.X, p.ZZ);
+    r.Y = fe_mul(p.Y, p.ZZZ);
+    r.Z = p.ZZ;
+    return r;
+}
+
 // Same group element?  (cross-multiplied comparison, no inversion)
 template <class C>
 BPP_HD bool jac_eq(const Jac<C>& p, const Jac<C>& q) {

@@ -186,6 +186,16 @@ BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 // Montgomery square: the NL(NL-1)/2 cross products are computed once and doubled.
 template <class P>
 BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+#if defined(BPP_SQR_OPAQUE) && defined(__HIP_DEVICE_COMPILE__)
+    // hide from the compiler that both operands are equal: it otherwise merges a_i*a_j with a_j*a_i into
+    // a doubled half-product schedule that issues fewer v_mad_u64_u32 but runs slower (profiles/ubench)
+    Fe<P> b = a;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) asm volatile("" : "+v"(b.l[i]));
+    return fe_mul(a, b);
+#elif defined(BPP_SQR_VIA_MUL)
+    return fe_mul(a, a);
+#endif
     constexpr int NL = P::NL;
     uint32_t T[2 * NL];
     uint64_t carry = 0;

@@ -47,7 +47,15 @@ __global__ void __launch_bounds__(64) k_dbg_point(int op, const uint32_t* a, con
         case 1: r = jac_madd(jac_from_aff(p), q); break;
         case 2: r = jac_dbl(jac_from_aff(p)); break;
         case 3: r = jac_madd(jac_dbl(jac_from_aff(p)), q); break;  // non-trivial Z
-        default: r = jac_add(jac_dbl(jac_from_aff(p)), jac_dbl(jac_from_aff(q))); break;
+        case 4: r = jac_add(jac_dbl(jac_from_aff(p)), jac_dbl(jac_from_aff(q))); break;
+        default: {  // XYZZ accumulator: inf + p + q + p
+            Xyzz<C> acc = xyzz_inf<C>();
+            acc = xyzz_madd(acc, p);
+            acc = xyzz_madd(acc, q);
+            acc = xyzz_madd(acc, p);
+            r = xyzz_to_jac(acc);
+            break;
+        }
     }
     aff_to_wire(jac_to_aff(r), wr);
     for (int t = 0; t < WW; t++) out[i * WW + t] = wr[t];

@@ -35,7 +35,7 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
 }
 
 struct WsLayout {
-    size_t pts, bad, scalars, fpart, vpart, total;
+    size_t pts, bad, scalars, fpart, vpart, vtbl, total;
 };
 
 template <class C>
@@ -57,7 +57,9 @@ struct VerifyImpl {
         w.fpart = o;
         o += al(count * blocks_per_proof(s, count) * 3 * N * 4);
         w.vpart = o;
-        o += al(count * 3 * N * 4);
+        o += al(count * s.NV * 3 * N * 4);
+        w.vtbl = o;
+        o += al(count * s.NV * 8 * 3 * N * 4);
         w.total = o;
         return w;
     }
@@ -120,6 +122,7 @@ struct VerifyImpl {
                                        : reinterpret_cast<uint32_t*>(ws + L.scalars);
         uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
         uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
+        uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
         const unsigned bpp_ = blocks_per_proof(s, count);
         const size_t npts = count * s.NV;
         hipEvent_t* ev = nullptr;
@@ -141,11 +144,11 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3(bpp_, (unsigned)count), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
                            s, w_sc, v->table.u32(), w_fp);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_var_msm<C>, dim3((unsigned)count), dim3(VAR_BLOCK), VAR_BLOCK * 3 * N * 4, st, s, w_sc,
-                           w_pts, w_vp);
+        hipLaunchKernelGGL(k_var_msm<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_sc, w_pts, w_vt,
+                           w_vp, npts);
         if (ev) HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_fp, bpp_, w_vp, w_bad, d_ok,
-                           reinterpret_cast<uint32_t*>(d_out_result), count);
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * 3 * N * 4, st, w_fp, bpp_, w_vp, s.NV,
+                           w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         if (ev) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());
         return BPP_OK;

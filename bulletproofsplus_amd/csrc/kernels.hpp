@@ -32,6 +32,13 @@ constexpr unsigned MSM_BLOCK = 64;
 constexpr unsigned VS_BLOCK = 256;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
+// minimum waves per SIMD the register allocator must leave room for (512 VGPRs / waves)
+#ifndef BPP_FIXED_WAVES
+#define BPP_FIXED_WAVES 2
+#endif
+#ifndef BPP_VAR_WAVES
+#define BPP_VAR_WAVES 2
+#endif
 
 // ---- small helpers -----------------------------------------------------------------------------------
 
@@ -461,85 +468,160 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
 // that.  partials: [count][gridDim.x] jacobians.
 template <class C>
-__global__ void __launch_bounds__(FIXED_BLOCK) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
+__global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials) {
     constexpr int N = C::Fp::N;
     extern __shared__ __align__(16) uint32_t lds[];
     const size_t b = blockIdx.y;
     const uint32_t* sc = scalars + b * (size_t)s.N * 8;
     const uint32_t mask = (1u << s.c) - 1u;
-    Jac<C> acc = jac_inf<C>();
-    for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < s.NF; f += gridDim.x * blockDim.x) {
-        uint32_t w[10];
-        ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, w);
-        w[8] = 0;
-        w[9] = 0;
-        // + bias K = sum_j half * 2^(c j): window j of (scalar + K) minus half is the signed digit
-        {
-            uint32_t carry = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
+    // software pipeline: the table entry of step t+1 is gathered while the mixed addition of step t runs
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = s.W;  // forces the first scalar load
+    uint32_t w[10];
+    bool have = false;   // a prefetched entry is pending
+    bool nneg = false;   // ... and must be negated when consumed
+    uint32_t raw[2 * N]; // its packed words, untouched until consumption so the gather stays in flight
+    auto fetch = [&]() {
+        have = false;
+        while (true) {
+            if (j == s.W) {
+                if (f >= s.NF) return;
+                ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, w);
+                w[8] = 0;
+                w[9] = 0;
+                // + bias K = sum_j half * 2^(c j): window j of (scalar + K) minus half is the signed digit
+                uint32_t carry = 0;
 #pragma unroll
-            for (int t = 0; t < 10; t++) {
-                uint64_t x = (uint64_t)w[t] + s.bias[t] + carry;
-                w[t] = (uint32_t)x;
-                carry = (uint32_t)(x >> 32);
+                for (int t = 0; t < 10; t++) {
+                    uint64_t x = (uint64_t)w[t] + s.bias[t] + carry;
+                    w[t] = (uint32_t)x;
+                    carry = (uint32_t)(x >> 32);
+                }
+                j = 0;
             }
-        }
-        const uint32_t* tf = table + ((size_t)f * s.W * s.half) * 2 * N;
-        for (uint32_t j = 0; j < s.W; j++) {
             const int32_t dg = (int32_t)(w[0] & mask) - (int32_t)s.half;
-            // shift the 320-bit value right by c
 #pragma unroll
             for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
             w[9] >>= s.c;
+            const uint32_t jj = j++;
+            const uint32_t ff = f;
+            if (j == s.W) f += stride;
             if (dg != 0) {
                 const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
-                Aff<C> q = aff_ldg<C>(tf + ((size_t)j * s.half + (mag - 1)) * 2 * N);
-                if (dg < 0) q.y = fe_neg(q.y);
-                acc = jac_madd(acc, q);
+                ld_words<2 * N>(table + (((size_t)ff * s.W + jj) * s.half + (mag - 1)) * 2 * N, raw);
+                nneg = dg < 0;
+                have = true;
+                return;
             }
         }
+    };
+    fetch();
+    while (have) {
+        Aff<C> cur = aff_load<C>(raw);
+        if (nneg) cur.y = fe_neg(cur.y);
+        fetch();
+        acc = xyzz_madd(acc, cur);
     }
-    acc = block_reduce_jac<C>(acc, lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (b * gridDim.x + blockIdx.x) * 3 * N, acc);
+    Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (b * gridDim.x + blockIdx.x) * 3 * N, sum);
 }
 
-// Proof-dependent part: the 3 + 2k + m points carried by the proof / commitments, one scalar
-// multiplication per lane, one block per proof.  partial: [count] jacobians.
+// Proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments.  One lane per
+// (proof, point) so that every lane of every wave is busy; fixed 4-bit signed windows: 65 digits in
+// [-8, 8) from (scalar + 0x88..8), a lane-private table of 1..8 multiples (jacobian, in HBM scratch, L2
+// resident), then 4 doublings + 1 addition per window.  out / tbl are indexed by item = proof * NV + v.
 template <class C>
-__global__ void __launch_bounds__(VAR_BLOCK) k_var_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
-                          const uint32_t* __restrict__ proof_pts, uint32_t* __restrict__ partial) {
+__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
+                                                       const uint32_t* __restrict__ proof_pts,
+                                                       uint32_t* __restrict__ tbl, uint32_t* __restrict__ out,
+                                                       size_t items) {
     constexpr int N = C::Fp::N;
-    extern __shared__ __align__(16) uint32_t lds[];
-    const size_t b = blockIdx.x;
-    const uint32_t* sc = scalars + b * (size_t)s.N * 8;
-    Jac<C> acc = jac_inf<C>();
-    for (uint32_t v = threadIdx.x; v < s.NV; v += blockDim.x) {
-        uint32_t k[8];
-        ld_words<8>(sc + (size_t)var_term_index(s, v) * 8, k);
-        Aff<C> p = aff_ldg<C>(proof_pts + (b * s.NV + v) * 2 * N);
-        acc = jac_add(acc, aff_mul_words(p, k, 8));
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= items) return;
+    const size_t b = item / s.NV;
+    const uint32_t v = (uint32_t)(item % s.NV);
+    uint32_t w[9];
+    ld_words<8>(scalars + (b * s.N + var_term_index(s, v)) * 8, w);
+    w[8] = 0;
+    {   // + 0x8888...8 (65 nibbles)
+        uint32_t carry = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const uint32_t kw = t < 8 ? 0x88888888u : 0x8u;
+            uint64_t x = (uint64_t)w[t] + kw + carry;
+            w[t] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
     }
-    acc = block_reduce_jac<C>(acc, lds);
-    if (threadIdx.x == 0) jac_stg<C>(partial + b * 3 * N, acc);
+    const Aff<C> p = aff_ldg<C>(proof_pts + item * 2 * N);
+    uint32_t* T = tbl + item * 8 * 3 * N;
+    {
+        Jac<C> t1 = jac_from_aff(p);
+        Jac<C> t2 = aff_dbl(p);
+        Jac<C> t3 = jac_madd(t2, p);
+        Jac<C> t4 = jac_dbl(t2);
+        jac_stg<C>(T, t1);
+        jac_stg<C>(T + 3 * N, t2);
+        jac_stg<C>(T + 2 * 3 * N, t3);
+        jac_stg<C>(T + 3 * 3 * N, t4);
+        Jac<C> t5 = jac_madd(t4, p);
+        Jac<C> t6 = jac_dbl(t3);
+        jac_stg<C>(T + 4 * 3 * N, t5);
+        jac_stg<C>(T + 5 * 3 * N, t6);
+        jac_stg<C>(T + 6 * 3 * N, jac_madd(t6, p));
+        jac_stg<C>(T + 7 * 3 * N, jac_dbl(t4));
+    }
+    Jac<C> acc = jac_inf<C>();
+    for (int j = 64; j >= 0; j--) {
+        // digit j = the nibble now at bits 256..259; then shift the 288-bit value left by one nibble
+        const int32_t dg = (int32_t)(w[8] & 15u) - 8;
+#pragma unroll
+        for (int t = 8; t > 0; t--) w[t] = (w[t] << 4) | (w[t - 1] >> 28);
+        w[0] <<= 4;
+        if (!acc.is_inf()) {
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+        }
+        if (dg != 0) {
+            const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
+            Jac<C> q = jac_ldg<C>(T + (size_t)(mag - 1) * 3 * N);
+            if (dg < 0) q.Y = fe_neg(q.Y);
+            acc = jac_add(acc, q);
+        }
+    }
+    jac_stg<C>(out + item * 3 * N, acc);
 }
 
 // expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError
-// (range/mod.rs:503-509, wip.rs:320-327).  A proof with an invalid point is rejected.
+// (range/mod.rs:503-509, wip.rs:320-327).  One wave per proof sums its `per` fixed partials and NV
+// proof-point products.  A proof with an invalid point is rejected.
 template <class C>
 __global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fixed_partials, uint32_t per,
-                           const uint32_t* __restrict__ var_partial, const uint32_t* __restrict__ bad,
-                           uint32_t* __restrict__ ok, uint32_t* __restrict__ wire_result, size_t count) {
+                                                 const uint32_t* __restrict__ var_partials, uint32_t nv,
+                                                 const uint32_t* __restrict__ bad, uint32_t* __restrict__ ok,
+                                                 uint32_t* __restrict__ wire_result) {
     constexpr int N = C::Fp::N;
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= count) return;
-    Jac<C> acc = jac_ldg<C>(var_partial + b * 3 * N);
-    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * 3 * N));
-    ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
-    if (wire_result) {
-        uint32_t w[2 * N + 2];
-        aff_to_wire(jac_to_aff(acc), w);
+    extern __shared__ __align__(16) uint32_t lds[];
+    const size_t b = blockIdx.x;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t t = threadIdx.x; t < per + nv; t += blockDim.x) {
+        const uint32_t* src = t < per ? fixed_partials + (b * per + t) * 3 * N : var_partials + (b * nv + (t - per)) * 3 * N;
+        acc = jac_add(acc, jac_ldg<C>(src));
+    }
+    acc = block_reduce_jac<C>(acc, lds);
+    if (threadIdx.x == 0) {
+        ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
+        if (wire_result) {
+            uint32_t w[2 * N + 2];
+            aff_to_wire(jac_to_aff(acc), w);
 #pragma unroll
-        for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
+            for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
+        }
     }
 }
 

@@ -70,7 +70,8 @@ def test_point_ops_match_oracle(cname, cid):
     n = len(pairs)
     dbl = lambda p: G.add(p, p)
     exp_fns = {0: lambda p, q: G.add(p, q), 1: lambda p, q: G.add(p, q), 2: lambda p, q: dbl(p),
-               3: lambda p, q: G.add(dbl(p), q), 4: lambda p, q: G.add(dbl(p), dbl(q))}
+               3: lambda p, q: G.add(dbl(p), q), 4: lambda p, q: G.add(dbl(p), dbl(q)),
+               5: lambda p, q: G.add(G.add(p, q), p)}
     for op, fn in exp_fns.items():
         out = np.zeros_like(A)
         rc = _lib.lib().bpp_debug_point_op(a.handle, op, A.ctypes.data, Bw.ctypes.data, n, out.ctypes.data)
