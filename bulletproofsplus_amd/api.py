@@ -142,6 +142,18 @@ class MulVec:
         return out
 
 
+def msm_pippenger(arith: Arith, scalars, points, window_bits: int = 0) -> np.ndarray:
+    """MulVec::calculate through the bucket-method pipeline (any n; window_bits 0 = chosen from n)."""
+    sc = scalars_to_wire(scalars)
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, arith.PW)
+    if sc.shape[0] != pts.shape[0]:
+        raise RuntimeError("mulvec: lengths of scalars and points must match")
+    out = np.zeros(arith.PW, dtype=np.uint64)
+    check(_lib.lib().bpp_msm_pippenger(arith.handle, _ptr(sc), _ptr(pts), sc.shape[0], window_bits, _ptr(out)),
+          "bpp_msm_pippenger")
+    return out
+
+
 def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
     """`len(lens)` independent MulVecs in one launch."""
     sc = scalars_to_wire(scalars)

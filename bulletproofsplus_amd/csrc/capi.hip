@@ -44,6 +44,15 @@ extern "C" int bpp_msm(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* po
     return bpp_msm_batch(ctx, scalars, points, &len, 1, out);
 }
 
+extern "C" int bpp_msm_pippenger(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n,
+                                 int window_bits, uint64_t* out) {
+    if (!ctx || !out || (n && (!scalars || !points))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::msm_pippenger(scalars, points, n, window_bits, out);
+    });
+}
+
 extern "C" int bpp_scalar_mul_batch(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n,
                                     uint64_t* out) {
     if (!ctx || !out || (n && (!scalars || !points))) return fail(BPP_E_ARG, "null argument");

@@ -3,6 +3,7 @@
 // bpp_range_verify (single proof, no tables) and the device unit-test hooks.
 #pragma once
 #include "host_util.hpp"
+#include "pippenger.hpp"
 
 namespace bpp {
 
@@ -72,6 +73,9 @@ struct MsmImpl {
                              uint64_t* out, hipStream_t st) {
         const size_t count = offsets.size() - 1;
         if (count == 0) return BPP_OK;
+        if (count == 1 && offsets[1] - offsets[0] >= PIPPENGER_MIN_N)
+            return msm_pippenger_dev(d_scalars + offsets[0] * 8, d_points + offsets[0] * 2 * N, offsets[1] - offsets[0],
+                                     0, out, st);
         size_t maxlen = 0;
         for (size_t c = 0; c < count; c++) maxlen = std::max<size_t>(maxlen, offsets[c + 1] - offsets[c]);
         const unsigned block = MSM_BLOCK;
@@ -89,6 +93,41 @@ struct MsmImpl {
         HIPCHK(hipMemcpyAsync(out, dout.p, count * WW * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         return BPP_OK;
+    }
+
+    // one large MulVec through the bucket method (pippenger.hpp); window_bits = 0 picks it from n
+    static constexpr size_t PIPPENGER_MIN_N = 4096;
+    static int msm_pippenger_dev(const uint32_t* d_scalars, const uint32_t* d_points, size_t n, int window_bits,
+                                 uint64_t* out, hipStream_t st) {
+        if (n >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "n too large");
+        const PipShape ps = pip_shape(n, window_bits ? window_bits : pip_pick_c(n));
+        const PipWorkspace pw = pip_workspace<C>(ps);
+        DevBuf ws, res, dout;
+        HIPCHK(ws.alloc(pw.total));
+        HIPCHK(res.alloc(3 * N * 4));
+        HIPCHK(dout.alloc(WW * 4));
+        HIPCHK(pip_launch<C>(ps, d_scalars, d_points, static_cast<uint8_t*>(ws.p), nullptr, 0, res.u32(), st));
+        hipLaunchKernelGGL(k_jac_reduce<C>, dim3(1), dim3(64), 0, st, res.u32(), 1u, dout.u32(), (size_t)1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out, dout.p, WW * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return BPP_OK;
+    }
+
+    // explicit window width (tests sweep it); host pointers
+    static int msm_pippenger(const uint64_t* scalars, const uint64_t* points, size_t n, int window_bits, uint64_t* out) {
+        if (window_bits && (window_bits < 2 || window_bits > 16)) return fail(BPP_E_ARG, "window_bits must be in [2, 16]");
+        if (n == 0) {
+            std::memset(out, 0, WW * 4);
+            out[PW - 1] = 1;
+            return BPP_OK;
+        }
+        DevBuf dsc, dpt;
+        int rc = upload_scalars<C>(scalars, n, dsc, nullptr);
+        if (rc) return rc;
+        rc = upload_points<C>(points, n, dpt, nullptr);
+        if (rc) return rc;
+        return msm_pippenger_dev(dsc.u32(), dpt.u32(), n, window_bits, out, nullptr);
     }
 
     static int msm_batch(const uint64_t* scalars, const uint64_t* points, const uint32_t* lens, size_t count,

@@ -1,0 +1,259 @@
+// pippenger.hpp -- bucket-method MulVec for LARGE variable-base inputs on gfx950.
+//
+// The reference's MulVec::calculate (src/bls12_381/building_block/mulvec.rs:20-33) is one scalar
+// multiplication per term.  For the sizes the reference itself produces (N <= 2 089) the data-parallel
+// restatement in kernels.hpp (k_msm_naive_partial) already finishes in one scalar-mult latency; this file
+// is the path for N in the tens of thousands and up (bpp_msm on big inputs, and the combined batch check
+// of impl_verify.hpp, which is one MulVec over every proof-carried point of a batch).
+//
+// Signed c-bit windows (digit j of scalar + bias, minus 2^(c-1)), W = ceil(258 / c) windows, 2^(c-1)
+// buckets per window.  Pipeline (all on one stream, no host round trips):
+//   k_pip_digits   per point: W digits -> key (bucket, sign); bucket histogram with returning atomics, the
+//                  returned value is the point's slot inside its bucket
+//   k_pip_scan     per window: exclusive prefix sum of the histogram (LDS, one block per window)
+//   k_pip_scatter  per (window, point): sorted[offset[bucket] + slot] = point index | sign
+//   k_pip_buckets  per (window, bucket): XYZZ running sum of its points (gathered from HBM)
+//   k_pip_windows  per window: sum_k (k+1) * B_k  by per-thread running sums over bucket segments, a small
+//                  scalar multiplication for the segment offset, and an LDS tree over the block
+//   k_pip_final    Horner over the W window sums (c doublings between windows), written as a jacobian
+#pragma once
+#include "kernels.hpp"
+
+namespace bpp {
+
+struct PipShape {
+    uint32_t n;                // points
+    uint32_t c, W, half;       // window bits, windows, buckets per window 2^(c-1)
+    uint32_t bias[10];         // sum_j half * 2^(c j)
+};
+
+inline PipShape pip_shape(size_t n, int c) {
+    PipShape s;
+    s.n = (uint32_t)n;
+    s.c = (uint32_t)c;
+    s.W = (258 + c - 1) / c;
+    s.half = 1u << (c - 1);
+    for (int t = 0; t < 10; t++) s.bias[t] = 0;
+    for (uint32_t j = 0; j < s.W; j++) {
+        const uint32_t bit = s.c * j + (s.c - 1);
+        s.bias[bit >> 5] |= 1u << (bit & 31);
+    }
+    return s;
+}
+
+// window width for n points: about 16 points per bucket, within [7, 16]
+inline int pip_pick_c(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 3;
+    return c < 7 ? 7 : (c > 16 ? 16 : c);
+}
+
+constexpr uint32_t PIP_EMPTY = 0xffffffffu;
+
+// keys / slots: [W][n]; counts: [W][half] (zeroed by the caller).  (Templated on the curve only to get
+// vague linkage: this header is included by several translation units.)
+template <class C>
+__global__ void __launch_bounds__(256) k_pip_digits(PipShape s, const uint32_t* __restrict__ scalars,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ slots,
+                                                    uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    uint32_t w[10];
+    ld_words<8>(scalars + (size_t)i * 8, w);
+    w[8] = 0;
+    w[9] = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        uint64_t x = (uint64_t)w[t] + s.bias[t] + carry;
+        w[t] = (uint32_t)x;
+        carry = (uint32_t)(x >> 32);
+    }
+    const uint32_t mask = (1u << s.c) - 1u;
+    for (uint32_t j = 0; j < s.W; j++) {
+        const int32_t dg = (int32_t)(w[0] & mask) - (int32_t)s.half;
+#pragma unroll
+        for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
+        w[9] >>= s.c;
+        uint32_t key = PIP_EMPTY, slot = 0;
+        if (dg != 0) {
+            const uint32_t b = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
+            slot = atomicAdd(&counts[(size_t)j * s.half + b], 1u);
+            key = (b << 1) | (dg < 0 ? 1u : 0u);
+        }
+        keys[(size_t)j * s.n + i] = key;
+        slots[(size_t)j * s.n + i] = slot;
+    }
+}
+
+// one block per window: offsets[j][b] = exclusive prefix sum of counts[j][.]
+template <class C>
+__global__ void __launch_bounds__(1024) k_pip_scan(PipShape s, const uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t part[1024];
+    const uint32_t j = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (s.half + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = t * per, hi = min(lo + per, s.half);
+    const uint32_t* cj = counts + (size_t)j * s.half;
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += cj[b];
+    part[t] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the per-thread sums
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    uint32_t* oj = offsets + (size_t)j * s.half;
+    for (uint32_t b = lo; b < hi; b++) {
+        oj[b] = run;
+        run += cj[b];
+    }
+}
+
+// sorted: [W][n] (only the first sum(counts[j]) entries of each row are written)
+template <class C>
+__global__ void __launch_bounds__(256) k_pip_scatter(PipShape s, const uint32_t* __restrict__ keys,
+                                                     const uint32_t* __restrict__ slots,
+                                                     const uint32_t* __restrict__ offsets,
+                                                     uint32_t* __restrict__ sorted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= s.n) return;
+    const uint32_t key = keys[(size_t)j * s.n + i];
+    if (key == PIP_EMPTY) return;
+    const uint32_t b = key >> 1;
+    sorted[(size_t)j * s.n + offsets[(size_t)j * s.half + b] + slots[(size_t)j * s.n + i]] = (i << 1) | (key & 1u);
+}
+
+// one thread per (window, bucket): bucket sum as a jacobian in buckets[j][b]
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32_t* __restrict__ points,
+                                                        const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ buckets) {
+    constexpr int N = C::Fp::N;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)s.W * s.half) return;
+    const uint32_t j = (uint32_t)(gid / s.half);
+    const uint32_t beg = offsets[gid], cnt = counts[gid];
+    const uint32_t* row = sorted + (size_t)j * s.n;
+    Xyzz<C> acc = xyzz_inf<C>();
+    for (uint32_t t = 0; t < cnt; t++) {
+        const uint32_t e = row[beg + t];
+        Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
+        if (e & 1u) q.y = fe_neg(q.y);
+        acc = xyzz_madd(acc, q);
+    }
+    jac_stg<C>(buckets + gid * 3 * N, xyzz_to_jac(acc));
+}
+
+// one block per window: R_j = sum_b (b + 1) * B_b.  Thread t owns the segment [t*S, (t+1)*S) with
+// S = half / blockDim.x (>= 1): descending running sums give sum (b - lo + 1) B_b and sum B_b, the
+// segment offset lo is applied with a short double-and-add, an LDS tree adds the threads.
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_pip_windows(PipShape s, const uint32_t* __restrict__ buckets,
+                                                        uint32_t* __restrict__ window_sums) {
+    constexpr int N = C::Fp::N;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t j = blockIdx.x, t = threadIdx.x;
+    const uint32_t S = max(1u, s.half / blockDim.x);
+    const uint32_t lo = t * S;
+    Jac<C> total = jac_inf<C>();
+    if (lo < s.half) {
+        const uint32_t hi = min(lo + S, s.half);
+        const uint32_t* bj = buckets + (size_t)j * s.half * 3 * N;
+        Jac<C> run = jac_inf<C>(), acc = jac_inf<C>();
+        for (uint32_t b = hi; b-- > lo;) {
+            run = jac_add(run, jac_ldg<C>(bj + (size_t)b * 3 * N));
+            acc = jac_add(acc, run);
+        }
+        // + lo * run
+        Jac<C> off = jac_inf<C>();
+        for (int bit = 31; bit >= 0; bit--) {
+            off = jac_dbl(off);
+            if ((lo >> bit) & 1u) off = jac_add(off, run);
+        }
+        total = jac_add(acc, off);
+    }
+    total = block_reduce_jac<C>(total, lds);
+    if (t == 0) jac_stg<C>(window_sums + (size_t)j * 3 * N, total);
+}
+
+// Horner over the windows; the result is ADDED to `extra` partials (may be none) and written as one
+// jacobian to out.  A single lane: about 258 sequential doublings.
+template <class C>
+__global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __restrict__ window_sums,
+                                                  const uint32_t* __restrict__ extra, uint32_t n_extra,
+                                                  uint32_t* __restrict__ out) {
+    constexpr int N = C::Fp::N;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t j = s.W; j-- > 0;) {
+        if (!acc.is_inf())
+            for (uint32_t t = 0; t < s.c; t++) acc = jac_dbl(acc);
+        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)j * 3 * N));
+    }
+    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + (size_t)t * 3 * N));
+    jac_stg<C>(out, acc);
+}
+
+struct PipWorkspace {
+    size_t keys, slots, sorted, counts, offsets, buckets, wsums, total;
+};
+template <class C>
+inline PipWorkspace pip_workspace(const PipShape& s) {
+    constexpr int N = C::Fp::N;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    PipWorkspace w;
+    size_t o = 0;
+    w.keys = o;
+    o += al((size_t)s.W * s.n * 4);
+    w.slots = o;
+    o += al((size_t)s.W * s.n * 4);
+    w.sorted = o;
+    o += al((size_t)s.W * s.n * 4);
+    w.counts = o;
+    o += al((size_t)s.W * s.half * 4);
+    w.offsets = o;
+    o += al((size_t)s.W * s.half * 4);
+    w.buckets = o;
+    o += al((size_t)s.W * s.half * 3 * N * 4);
+    w.wsums = o;
+    o += al((size_t)s.W * 3 * N * 4);
+    w.total = o;
+    return w;
+}
+
+// Enqueues the whole pipeline on `st`.  d_out: one jacobian (3N words).  d_extra: n_extra jacobians added in.
+template <class C>
+inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const uint32_t* d_points, uint8_t* d_ws,
+                             const uint32_t* d_extra, uint32_t n_extra, uint32_t* d_out, hipStream_t st) {
+    constexpr int N = C::Fp::N;
+    const PipWorkspace w = pip_workspace<C>(s);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(d_ws + w.keys);
+    uint32_t* slots = reinterpret_cast<uint32_t*>(d_ws + w.slots);
+    uint32_t* sorted = reinterpret_cast<uint32_t*>(d_ws + w.sorted);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(d_ws + w.counts);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(d_ws + w.offsets);
+    uint32_t* buckets = reinterpret_cast<uint32_t*>(d_ws + w.buckets);
+    uint32_t* wsums = reinterpret_cast<uint32_t*>(d_ws + w.wsums);
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)s.W * s.half * 4, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pip_digits<C>, dim3((s.n + 255) / 256), dim3(256), 0, st, s, d_scalars, keys, slots, counts);
+    hipLaunchKernelGGL(k_pip_scan<C>, dim3(s.W), dim3(1024), 0, st, s, counts, offsets);
+    hipLaunchKernelGGL(k_pip_scatter<C>, dim3((s.n + 255) / 256, s.W), dim3(256), 0, st, s, keys, slots, offsets, sorted);
+    const size_t nb = (size_t)s.W * s.half;
+    hipLaunchKernelGGL(k_pip_buckets<C>, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, st, s, d_points, sorted,
+                       offsets, counts, buckets);
+    hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(128), 128 * 3 * N * 4, st, s, buckets, wsums);
+    hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(64), 0, st, s, wsums, d_extra, n_extra, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace bpp

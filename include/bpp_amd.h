@@ -63,6 +63,11 @@ int bpp_point_words(int curve_id);
  * n == 0 gives the point at infinity (Point::zero()).  Host pointers. */
 int bpp_msm(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_t n, uint64_t *out);
 
+/* The same MulVec through the bucket (Pippenger) pipeline regardless of n (bpp_msm switches to it by
+ * itself from n = 4096 up); window_bits in [2, 16], 0 = chosen from n.  Host pointers. */
+int bpp_msm_pippenger(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_t n, int window_bits,
+                      uint64_t *out);
+
 /* `count` independent MulVecs in one launch: MulVec c has lens[c] terms starting at offset
  * sum(lens[0..c)).  out: count points.  (The fold of src/weighted_inner_product_proof.rs:151-163 is
  * 2 n' MulVecs of length 2.)  Host pointers. */

@@ -156,3 +156,39 @@ def test_mulvec_matches_oracle(cname, cid):
     bad[0, 0] ^= 1
     with pytest.raises(B.BppError):
         B.msm_batch(a, [3], bad, [1])
+
+
+@pytest.mark.parametrize("cname,cid", CURVES)
+def test_pippenger_matches_naive_and_oracle(cname, cid):
+    """Bucket-method MulVec (pippenger.hpp) == data-parallel naive MulVec == oracle, incl. collisions,
+    infinity, zero / tiny / huge scalars, every window width."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init(cid)
+    r = P.CURVES[cname]["r"]
+    rnd = random.Random(77)
+    opk = O.PublicKey(cid, 100)
+    base = np.concatenate([opk.gh, opk.G, opk.H, O.points_to_wire(cid, [None])])     # 203 points, with collisions
+    n = 300
+    pts = base[[rnd.randrange(base.shape[0]) for _ in range(n)]]
+    scs = [rnd.randrange(r) for _ in range(n)]
+    scs[:8] = [0, 1, 2, r - 1, r - 2, 5, r - 5, (1 << 255) % r]
+    pts[6] = pts[5]
+    exp = O.msm(cid, O.scalars_to_wire(scs), pts)
+    assert np.array_equal(B.msm_batch(a, scs, pts, [n])[0], exp)
+    for c in (0, 2, 3, 5, 8, 11, 13, 16):
+        assert np.array_equal(B.msm_pippenger(a, scs, pts, c), exp), c
+    # empty input and a single term
+    assert a.is_zero(B.msm_pippenger(a, [], np.zeros((0, a.PW), np.uint64)))
+    assert np.array_equal(B.msm_pippenger(a, [7], pts[9:10], 4), O.msm(cid, O.scalars_to_wire([7]), pts[9:10]))
+    # large n goes through the bucket path inside bpp_msm itself; checked against a structured identity:
+    # sum_i s_i * (k_i g) == (sum s_i k_i) g with the reference's known-dlog generators
+    big = 6000
+    idx = [rnd.randrange(100) for _ in range(big)]
+    ss = [rnd.randrange(r) for _ in range(big)]
+    bp = opk.G[idx]
+    tot = sum(s * 3 * (i + 1) for s, i in zip(ss, idx)) % r
+    mv = B.MulVec(a)
+    mv.add_scalars(ss)
+    mv.add_points(bp)
+    assert np.array_equal(mv.calculate(), O.point_mul(cid, opk.gh[0], tot))
