@@ -28,7 +28,8 @@ EXPORTS = [
     "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_commit", "bpp_range_prove", "bpp_range_verify",
     "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
     "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
-    "bpp_verifier_set_profiling", "bpp_verifier_profile",
+    "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_partial_bytes",
+    "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
 ]
 
 
@@ -79,6 +80,12 @@ def lib():
         L.bpp_verifier_dominant_kernel.restype = ctypes.c_char_p
         L.bpp_verifier_set_profiling.argtypes = [vp, i32]
         L.bpp_verifier_profile.argtypes = [vp, vp, vp, vp]
+        L.bpp_verifier_partial_bytes.argtypes = [vp]
+        L.bpp_verifier_partial_bytes.restype = sz
+        L.bpp_verifier_combined_workspace_bytes.argtypes = [vp, sz]
+        L.bpp_verifier_combined_workspace_bytes.restype = sz
+        L.bpp_verifier_run_combined.argtypes = [vp, vp, vp, sz, vp, u64, vp, vp, vp, sz, vp]
+        L.bpp_verifier_sum_partials.argtypes = [vp, vp, sz, vp, vp]
         L.bpp_debug_field_op.argtypes = [vp, i32, i32, vp, vp, sz, vp]
         L.bpp_debug_point_op.argtypes = [vp, i32, vp, vp, sz, vp]
         _lib = L

@@ -371,6 +371,34 @@ def _verifier_profile(self):
     return {k: float(ms[i]) for i, k in enumerate(STAGES)}, passes.value, bpp_.value
 
 
+def _verifier_partial_bytes(self) -> int:
+    return _lib.lib().bpp_verifier_partial_bytes(self.handle)
+
+
+def _verifier_combined_workspace_bytes(self, count: int) -> int:
+    return _lib.lib().bpp_verifier_combined_workspace_bytes(self.handle, count)
+
+
+def _verifier_run_combined_device(self, d_points: int, d_scalars: int, count: int, seed: int, d_out_partial: int,
+                                  d_ok: int, d_workspace: int, workspace_bytes: int, stream: int = 0,
+                                  d_challenges: int = 0):
+    """Combined batch check (NOT the reference's per-proof semantics, see include/bpp_amd.h): one weighted
+    sum of the batch's verification MulVecs.  d_ok[0] == 0 iff it is the identity."""
+    check(_lib.lib().bpp_verifier_run_combined(self.handle, d_points, d_scalars, count, d_challenges or None,
+                                               ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), d_out_partial, d_ok,
+                                               d_workspace, workspace_bytes, stream or None),
+          "bpp_verifier_run_combined")
+
+
+def _verifier_sum_partials_device(self, d_partials: int, n: int, d_ok: int, stream: int = 0):
+    check(_lib.lib().bpp_verifier_sum_partials(self.handle, d_partials, n, d_ok, stream or None),
+          "bpp_verifier_sum_partials")
+
+
+BatchVerifier.partial_bytes = _verifier_partial_bytes
+BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
+BatchVerifier.run_combined_device = _verifier_run_combined_device
+BatchVerifier.sum_partials_device = _verifier_sum_partials_device
 BatchVerifier.set_profiling = _verifier_set_profiling
 BatchVerifier.profile = _verifier_profile
 

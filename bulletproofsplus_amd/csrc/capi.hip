@@ -137,6 +137,41 @@ extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const
     });
 }
 
+// ---- combined batch check ------------------------------------------------------------------------------
+extern "C" size_t bpp_verifier_partial_bytes(const bpp_verifier* v) {
+    if (!v) return 0;
+    return v->ctx.curve == BPP_BLS12_381_G1 ? 3 * 12 * 4 : 3 * 8 * 4;
+}
+extern "C" size_t bpp_verifier_combined_workspace_bytes(const bpp_verifier* v, size_t count) {
+    if (!v) return 0;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::comb_layout(v->s, count).total;
+        return 0;
+    });
+    return r;
+}
+extern "C" int bpp_verifier_run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars,
+                                         size_t count, const uint64_t* d_challenges, uint64_t seed,
+                                         void* d_out_partial, uint32_t* d_ok, void* d_workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (!v || !d_points || !d_scalars || !d_out_partial || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return fail(BPP_E_ARG, "empty batch");
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::run_combined(v, d_points, d_scalars, count, d_challenges, seed,
+                                                      static_cast<uint32_t*>(d_out_partial), d_ok, d_workspace,
+                                                      workspace_bytes, static_cast<hipStream_t>(stream));
+    });
+}
+extern "C" int bpp_verifier_sum_partials(bpp_verifier* v, const void* d_partials, size_t n, uint32_t* d_ok,
+                                         void* stream) {
+    if (!v || !d_partials || !d_ok) return fail(BPP_E_ARG, "null argument");
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::sum_partials(static_cast<const uint32_t*>(d_partials), n, d_ok,
+                                                      static_cast<hipStream_t>(stream));
+    });
+}
+
 extern "C" int bpp_verifier_set_profiling(bpp_verifier* v, int on) {
     if (!v) return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(v->ctx.device));

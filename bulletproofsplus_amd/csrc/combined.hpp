@@ -1,0 +1,117 @@
+// combined.hpp -- kernels of the COMBINED batch check ("final multiscalar check", SURVEY.md 8e mode B).
+//
+// Not a reference code path: the reference verifies one proof at a time (src/range/mod.rs:57-78) and has no
+// batch API.  For a batch of proofs p = 1..B with verification MulVecs  M_p = sum_t s_{p,t} * P_{p,t}
+// (each must be the identity), this mode checks the single equation   sum_p w_p * M_p == identity
+// with weights w_p from a stated deterministic stream (SplitMix64 of (seed, p), 128 bit, odd):
+//   * the 2mn+2 fixed generators are shared by every proof, so their terms collapse to ONE fixed-base
+//     MulVec with scalars S_f = sum_p w_p * s_{p,f}               (k_comb_fixed, then k_fixed_msm, count 1)
+//   * the proof-carried points form ONE variable-base MulVec of B * (3+2k+m) terms with scalars
+//     w_p * s_{p,v}                                                (k_comb_var_scalars, then pippenger.hpp)
+// All-valid batches always pass; a batch with an invalid proof fails except with probability ~2^-128 over
+// the weights, and the caller then falls back to the per-proof path (bpp_verifier_run) for exact verdicts.
+// Across GPUs each rank produces one jacobian partial; they are exchanged once and summed
+// (k_comb_sum_partials) -- the "single reduce over xGMI" of the north star.
+#pragma once
+#include "kernels.hpp"
+
+namespace bpp {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// weights[p]: Montgomery form, packed 8 words.  w_p = (splitmix64(seed + 2p) | 1) + 2^64 * splitmix64(seed + 2p + 1)
+template <class C>
+__global__ void __launch_bounds__(256) k_comb_weights(uint64_t seed, uint32_t* __restrict__ weights, size_t count) {
+    using P = typename C::Fr;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const uint64_t lo = splitmix64(seed + 2 * p) | 1ull, hi = splitmix64(seed + 2 * p + 1);
+    uint32_t w[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0};
+    Fe<P> x = fe_from_canonical<P>(w);
+    uint32_t o[8];
+    fe_store(x, o);
+    st_words<8>(weights + p * 8, o);
+}
+
+// out[item] = canonical(w_p * s[p][var_term_index(v)]),  item = p * NV + v
+template <class C>
+__global__ void __launch_bounds__(256) k_comb_var_scalars(VerifyShape s, const uint32_t* __restrict__ scalars,
+                                                          const uint32_t* __restrict__ weights,
+                                                          uint32_t* __restrict__ out, size_t items) {
+    using P = typename C::Fr;
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= items) return;
+    const size_t p = item / s.NV;
+    const uint32_t v = (uint32_t)(item % s.NV);
+    uint32_t w[8];
+    ld_words<8>(scalars + (p * s.N + var_term_index(s, v)) * 8, w);
+    Fe<P> x = fe_from_canonical<P>(w);
+    ld_words<8>(weights + p * 8, w);
+    x = fe_mul(x, fe_load<P>(w));
+    fe_to_canonical(x, w);
+    st_words<8>(out + item * 8, w);
+}
+
+// one block per fixed generator f: out[fixed_term_index(f)] = canonical(sum_p w_p * s[p][fixed_term_index(f)])
+template <class C>
+__global__ void __launch_bounds__(256) k_comb_fixed(VerifyShape s, const uint32_t* __restrict__ scalars,
+                                                    const uint32_t* __restrict__ weights, size_t count,
+                                                    uint32_t* __restrict__ out) {
+    using P = typename C::Fr;
+    using F = Fe<P>;
+    __shared__ F red[256];
+    const uint32_t f = blockIdx.x, t = threadIdx.x;
+    const uint32_t idx = fixed_term_index(s, f);
+    F acc = F::zero();
+    for (size_t p = t; p < count; p += blockDim.x) {
+        uint32_t w[8];
+        ld_words<8>(scalars + (p * s.N + idx) * 8, w);
+        F x = fe_from_canonical<P>(w);
+        ld_words<8>(weights + p * 8, w);
+        acc = fe_add(acc, fe_mul(x, fe_load<P>(w)));
+    }
+    red[t] = acc;
+    __syncthreads();
+    for (uint32_t h = blockDim.x >> 1; h >= 1; h >>= 1) {
+        if (t < h) red[t] = fe_add(red[t], red[t + h]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        uint32_t w[8];
+        fe_to_canonical(red[0], w);
+        st_words<8>(out + (size_t)idx * 8, w);
+    }
+}
+
+// verdict of one rank's share: ok = partial is the identity and no proof carried an invalid point
+template <class C>
+__global__ void __launch_bounds__(256) k_comb_verdict(const uint32_t* __restrict__ partial,
+                                                      const uint32_t* __restrict__ bad, size_t count,
+                                                      uint32_t* __restrict__ ok) {
+    int anybad = 0;
+    for (size_t p = threadIdx.x; p < count; p += blockDim.x) anybad |= (bad[p] != 0);
+    anybad = __syncthreads_or(anybad);
+    if (threadIdx.x == 0) {
+        Jac<C> acc = jac_ldg<C>(partial);
+        ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
+    }
+}
+
+// sum of n jacobian partials (one per rank) -> verdict (and the sum itself, optional)
+template <class C>
+__global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __restrict__ partials, uint32_t n,
+                                                          uint32_t* __restrict__ ok, uint32_t* __restrict__ out) {
+    constexpr int N = C::Fp::N;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t t = 0; t < n; t++) acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * 3 * N));
+    ok[0] = acc.is_inf() ? 0u : 1u;
+    if (out) jac_stg<C>(out, acc);
+}
+
+}  // namespace bpp

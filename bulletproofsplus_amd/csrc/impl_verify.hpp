@@ -1,7 +1,9 @@
 // impl_verify.hpp -- the batch verifier (bpp_verifier_*): window tables in HBM + one pass of the hot path
 // over a device-resident batch.  One instantiation per curve (tu_verify_*.hip).
 #pragma once
+#include "combined.hpp"
 #include "host_util.hpp"
+#include "pippenger.hpp"
 
 // stages of one pass, in launch order (bpp_verifier_profile reports one duration per stage)
 enum { BPP_STAGE_FROM_WIRE = 0, BPP_STAGE_SCALARS, BPP_STAGE_FIXED_MSM, BPP_STAGE_VAR_MSM, BPP_STAGE_FINALIZE,
@@ -76,6 +78,11 @@ struct VerifyImpl {
         DevBuf dfixed;
         rc = upload_points<C>(fixed.data(), s.NF, dfixed, nullptr);
         if (rc) return rc;
+        if (vs_lds_bytes<C>(s) > 64 * 1024) {
+            // above the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_verify_scalars<C>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
+        }
         bpp_verifier* v = new bpp_verifier();
         v->ctx = ctx;
         v->s = s;
@@ -138,8 +145,8 @@ struct VerifyImpl {
         const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
         const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
         if (ev) HIPCHK(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_verify_scalars<C>, dim3((unsigned)count), dim3(VS_BLOCK), 0, st, s,
-                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc);
+        hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
+                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3(bpp_, (unsigned)count), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
                            s, w_sc, v->table.u32(), w_fp);
@@ -150,6 +157,82 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * 3 * N * 4, st, w_fp, bpp_, w_vp, s.NV,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         if (ev) HIPCHK(hipEventRecord(ev[5], st));
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+
+    // ---- combined batch check (combined.hpp) ------------------------------------------------------------
+    struct CombLayout {
+        size_t pts, bad, scalars, weights, comb_sc, fpart, var_sc, pip, total;
+        PipShape ps;
+        unsigned fixed_blocks;
+    };
+    static CombLayout comb_layout(const VerifyShape& s, size_t count) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        CombLayout w;
+        const size_t items = count * s.NV;
+        w.ps = pip_shape(items, pip_pick_c(items));
+        w.fixed_blocks = blocks_per_proof(s, 1);
+        size_t o = 0;
+        w.pts = o;
+        o += al(items * 2 * N * 4);
+        w.bad = o;
+        o += al(count * 4);
+        w.scalars = o;
+        o += al(count * (size_t)s.N * 32);
+        w.weights = o;
+        o += al(count * 32);
+        w.comb_sc = o;
+        o += al((size_t)s.N * 32);
+        w.fpart = o;
+        o += al((size_t)w.fixed_blocks * 3 * N * 4);
+        w.var_sc = o;
+        o += al(items * 32);
+        w.pip = o;
+        o += al(pip_workspace<C>(w.ps).total);
+        w.total = o;
+        return w;
+    }
+
+    // d_out_partial: one jacobian (3N words, opaque to the caller) = this batch's weighted sum
+    static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                            const uint64_t* d_challenges, uint64_t seed, uint32_t* d_out_partial, uint32_t* d_ok,
+                            void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+        const VerifyShape& s = v->s;
+        const CombLayout L = comb_layout(s, count);
+        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+        if (count * s.NV >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "count too large");
+        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+        uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
+        uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
+        uint32_t* w_sc = reinterpret_cast<uint32_t*>(ws + L.scalars);
+        uint32_t* w_wt = reinterpret_cast<uint32_t*>(ws + L.weights);
+        uint32_t* w_cs = reinterpret_cast<uint32_t*>(ws + L.comb_sc);
+        uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
+        uint32_t* w_vs = reinterpret_cast<uint32_t*>(ws + L.var_sc);
+        const size_t items = count * s.NV;
+        HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+        HIPCHK(hipMemsetAsync(w_cs, 0, (size_t)s.N * 32, st));
+        hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
+                           reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
+        const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
+        const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+        hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
+                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
+        hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
+        hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks, 1), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st, s,
+                           w_cs, v->table.u32(), w_fp);
+        hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
+        HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
+        hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+
+    static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
+        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n, d_ok,
+                           (uint32_t*)nullptr);
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }

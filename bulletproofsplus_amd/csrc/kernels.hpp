@@ -29,7 +29,8 @@ namespace bpp {
 // launch geometry (threads per block) of the heavy kernels; the __launch_bounds__ below let the register
 // allocator use the whole 512-entry VGPR file at that occupancy instead of the 1024-thread default (128)
 constexpr unsigned MSM_BLOCK = 64;
-constexpr unsigned VS_BLOCK = 256;
+constexpr unsigned VS_PB = 8;                 // proofs per block of k_verify_scalars, 64 lanes each
+constexpr unsigned VS_BLOCK = VS_PB * 64;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
 // minimum waves per SIMD the register allocator must leave room for (512 VGPRs / waves)
@@ -236,42 +237,117 @@ __device__ Fe<P> sum_of_powers(const Fe<P>& x, uint32_t n, bool type2) {
 #define VS_MAXK 20
 #define VS_MAXM 64
 #define VS_MAXN 64
+#define VS_MAXCH 64   // indices per lane = mn / 64 (<= n)
 
-// One block per proof.  Writes the N MulVec scalars of that proof (canonical, 8 words each) in the
-// reference's MulVec order:
+// per-proof scratch of k_verify_scalars, carved from dynamic LDS (sizes depend on k, m, mn/64)
+template <class F>
+struct VsShared {
+    F* chsq;      // [k]    e_j^2
+    F* chinvsq;   // [k]    e_j^-2
+    F* ypw;       // [k+1]  y^(2^b)
+    F* yipw;      // [k+1]  y^-(2^b)
+    F* pz;        // [m]    (z^2)^(j+1)   (m > 1)
+    F* sy_lo;     // [CH]   prod_{low bits of l set} e^2  *  y^-l
+    F* sc_lo;     // [CH]   prod_{low bits of l unset} e^2
+    F* t_lo;      // [CH]   (2 y^-1)^l
+    F* tmp;       // [k+2]  prefix products of the batched inversion, then the e_j^-1
+    F* c;         // [8]    kGa, kHa, yinv, cG, zc, hmul, einv
+    __host__ __device__ static uint32_t elems(uint32_t k, uint32_t m, uint32_t CH) {
+        return 2 * k + 2 * (k + 1) + m + 3 * CH + (k + 2) + 8;
+    }
+    __device__ VsShared(F* base, uint32_t k, uint32_t m, uint32_t CH) {
+        chsq = base;
+        chinvsq = chsq + k;
+        ypw = chinvsq + k;
+        yipw = ypw + k + 1;
+        pz = yipw + k + 1;
+        sy_lo = pz + m;
+        sc_lo = sy_lo + CH;
+        t_lo = sc_lo + CH;
+        tmp = t_lo + CH;
+        c = tmp + k + 2;
+    }
+    __device__ F& kGa() { return c[0]; }
+    __device__ F& kHa() { return c[1]; }
+    __device__ F& yinv() { return c[2]; }
+    __device__ F& cG() { return c[3]; }
+    __device__ F& zc() { return c[4]; }
+    __device__ F& hmul() { return c[5]; }
+    __device__ F& einv() { return c[6]; }
+};
+
+// dynamic LDS bytes of one k_verify_scalars block (Fr elements are NL 32-bit words each)
+template <class C>
+inline size_t vs_lds_bytes(const VerifyShape& s) {
+    using F = Fe<typename C::Fr>;
+    const uint32_t CH = s.mn >= 64 ? s.mn / 64 : 1;
+    return ((size_t)VS_MAXN + (size_t)VS_PB * VsShared<F>::elems(s.k, s.m, CH)) * sizeof(F);
+}
+
+// VS_PB proofs per block, 64 lanes per proof.  Writes the N MulVec scalars of each proof (canonical, 8
+// words each) in the reference's MulVec order:
 //   m > 1 (range/mod.rs:481-490): [1, e^-1, e^-2, g_exp, h_exp, e_i^2 (k), e_i^-2 (k), G_exp (mn), H_exp (mn), V_exp (m)]
 //   m = 1 (wip.rs:298-307)      : [1, e,    e^2,  g_exp, h_exp, e_i^2 e^2,  e_i^-2 e^2, G_exp (n),  H_exp (n),  V_exp (1)]
 // proof_scalars: [r', s', delta'] per proof; challenges: [y, z, e, e_1..e_k] (per proof when
-// ch_stride != 0, shared otherwise).  Inversions are done on device (Fermat), one lane each.
+// ch_stride != 0, shared otherwise).
+// Phases: (A) one lane per proof inverts y, e, e_1..e_k with ONE Fermat inversion (Montgomery's trick);
+// (B) one lane per proof computes the per-proof constants, another the power tables; (B') the first
+// mn/64 lanes of each proof build three small per-proof tables; (C) 64 lanes per proof, mn/64 consecutive
+// indices each, three multiplications per index:
+//   G_exp[i] = cG - [kG allinv prod_{hi bits} e^2 y^-(i0+1)] * sy_lo[l]                (range/mod.rs:456-459)
+//   H_exp[i] = [pz y^(mn-i0) 2^(i0%n) cH] * t_lo[l] + z cH - [kH allinv prod_{hi unset} e^2] * sc_lo[l]   (:461-465)
+// with i = i0 + l, using s_vec[i] = allinv * prod_{bit b of i set} e^2_{k-1-b} (wip.rs:372-380 unrolled).
 template <class C>
 __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, const uint32_t* __restrict__ proof_scalars,
-                                 const uint32_t* __restrict__ challenges, uint32_t ch_stride,
-                                 uint32_t* __restrict__ out) {
+                                                             const uint32_t* __restrict__ challenges,
+                                                             uint32_t ch_stride, uint32_t* __restrict__ out,
+                                                             size_t count) {
     using P = typename C::Fr;
     using F = Fe<P>;
-    __shared__ F sh_chsq[VS_MAXK], sh_chinv[VS_MAXK], sh_ypw[VS_MAXK + 1], sh_yipw[VS_MAXK + 1];
-    __shared__ F sh_pz[VS_MAXM], sh_p2[VS_MAXN];
-    __shared__ F sh_allinv, sh_yinv, sh_einv, sh_cG, sh_kG, sh_kH, sh_cH, sh_z;
+    extern __shared__ __align__(16) uint32_t lds_raw[];
     const uint32_t tid = threadIdx.x;
-    const size_t b = blockIdx.x;
-    const uint32_t* ch = challenges + (size_t)ch_stride * b;
-    uint32_t* o = out + b * (size_t)s.N * 8;
     const uint32_t k = s.k, mn = s.mn;
+    const uint32_t CH = mn >= 64 ? mn / 64 : 1;      // indices per lane (power of two, <= n)
+    uint32_t cb = 0;
+    while ((1u << cb) < CH) cb++;
+    F* const lds_f = reinterpret_cast<F*>(lds_raw);
+    F* const sh_p2 = lds_f;                           // [VS_MAXN] 2^t, shared by the block's proofs
+    const uint32_t per_proof = VsShared<F>::elems(k, s.m, CH);
+    auto proof_lds = [&](uint32_t slot) { return VsShared<F>(lds_f + VS_MAXN + (size_t)slot * per_proof, k, s.m, CH); };
 
-    // phase A: inversions, one lane each (e_1..e_k, y, e) ; 2^t as field elements
-    if (tid < k + 2) {
-        uint32_t w[8];
-        const uint32_t src = tid < k ? 3 + tid : (tid == k ? 0 : 2);
-        ld_words<8>(ch + src * 8, w);
-        F x = fe_from_canonical<P>(w);
-        F xi = fe_inv(x);
-        if (tid < k) {
-            sh_chsq[tid] = fe_sqr(x);
-            sh_chinv[tid] = xi;
-        } else if (tid == k) {
-            sh_yinv = xi;
-        } else {
-            sh_einv = xi;
+    // ---- phase A: lanes 0..VS_PB-1 invert [y, e, e_1..e_k] of their proof; lanes 64.. build 2^t --------
+    if (tid < VS_PB) {
+        const size_t b = (size_t)blockIdx.x * VS_PB + tid;
+        if (b < count) {
+            VsShared<F> sh = proof_lds(tid);
+            const uint32_t* ch = challenges + (size_t)ch_stride * b;
+            // order: x_0 = y, x_1 = e, x_{2+j} = e_j ; zero entries are skipped (their "inverse" stays 0)
+            F acc = F::one();
+            for (uint32_t j = 0; j < k + 2; j++) {
+                uint32_t w[8];
+                ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
+                F x = fe_from_canonical<P>(w);
+                if (!x.is_zero()) acc = fe_mul(acc, x);
+                sh.tmp[j] = acc;
+            }
+            F inv = fe_inv(acc);
+            for (uint32_t j = k + 2; j-- > 0;) {
+                uint32_t w[8];
+                ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
+                F x = fe_from_canonical<P>(w);
+                F xi = F::zero();
+                if (!x.is_zero()) {
+                    xi = j ? fe_mul(inv, sh.tmp[j - 1]) : inv;
+                    inv = fe_mul(inv, x);
+                }
+                if (j == 0) sh.yinv() = xi;
+                else if (j == 1) sh.einv() = xi;
+                else {
+                    sh.chsq[j - 2] = fe_sqr(x);
+                    sh.chinvsq[j - 2] = fe_sqr(xi);
+                    sh.tmp[j] = xi;                        // e_{j-2}^-1 (slot j is no longer needed as a prefix)
+                }
+            }
         }
     } else if (tid >= 64 && tid < 64 + s.n && tid - 64 < VS_MAXN) {
         const uint32_t t = tid - 64;
@@ -281,141 +357,175 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
     }
     __syncthreads();
 
-    // phase B: per-proof constants (thread 0) ; power tables (thread 64, a different wave)
-    if (tid == 0) {
-        uint32_t w[8];
-        ld_words<8>(ch + 0, w);
-        F y = fe_from_canonical<P>(w);
-        ld_words<8>(ch + 8, w);
-        F z = fe_from_canonical<P>(w);
-        ld_words<8>(ch + 16, w);
-        F e = fe_from_canonical<P>(w);
-        ld_words<8>(proof_scalars + b * 24, w);
-        F rp = fe_from_canonical<P>(w);
-        ld_words<8>(proof_scalars + b * 24 + 8, w);
-        F sp = fe_from_canonical<P>(w);
-        ld_words<8>(proof_scalars + b * 24 + 16, w);
-        F dp = fe_from_canonical<P>(w);
-        F allinv = F::one();
-        for (uint32_t j = 0; j < k; j++) allinv = fe_mul(allinv, sh_chinv[j]);  // batch_invert's product
-        sh_allinv = allinv;
-        sh_z = z;
-        const F einv = sh_einv;
-        const F zsq = fe_sqr(z);
-        F head1, head2, g_exp, h_exp, lr_mul;
-        if (s.m == 1) {
-            // range/mod.rs:198-226 + wip.rs:254-295
-            const F esq = fe_sqr(e);
-            head1 = e;
-            head2 = esq;
-            sh_cG = fe_mul(fe_neg(z), esq);
-            sh_kG = fe_mul(fe_mul(rp, e), y);
-            sh_kH = fe_mul(sp, e);
-            sh_cH = esq;
-            const F y_n1 = fe_pow_u64(y, (uint64_t)s.n + 1);
-            F gc = F::zero();  // sum_{i<n} y^{i+1}
-            {
-                F cur = y;
-                for (uint32_t i = 0; i < s.n; i++) {
-                    gc = fe_add(gc, cur);
-                    cur = fe_mul(cur, y);
+    // ---- phase B: lane q: per-proof constants and head scalars; lane 64+q: power tables --------------
+    if (tid < VS_PB) {
+        const size_t b = (size_t)blockIdx.x * VS_PB + tid;
+        if (b < count) {
+            VsShared<F> sh = proof_lds(tid);
+            const uint32_t* ch = challenges + (size_t)ch_stride * b;
+            uint32_t* o = out + b * (size_t)s.N * 8;
+            uint32_t w[8];
+            ld_words<8>(ch + 0, w);
+            const F y = fe_from_canonical<P>(w);
+            ld_words<8>(ch + 8, w);
+            const F z = fe_from_canonical<P>(w);
+            ld_words<8>(ch + 16, w);
+            const F e = fe_from_canonical<P>(w);
+            ld_words<8>(proof_scalars + b * 24, w);
+            const F rp = fe_from_canonical<P>(w);
+            ld_words<8>(proof_scalars + b * 24 + 8, w);
+            const F sp = fe_from_canonical<P>(w);
+            ld_words<8>(proof_scalars + b * 24 + 16, w);
+            const F dp = fe_from_canonical<P>(w);
+            const F einv = sh.einv();
+            F allinv = F::one();                        // batch_invert's product of the e_j^-1
+            for (uint32_t j = 0; j < k; j++) allinv = fe_mul(allinv, sh.tmp[j + 2]);
+            const F zsq = fe_sqr(z);
+            F head1, head2, g_exp, h_exp, lr_mul, kG, kH, cH;
+            uint32_t wv[8];
+            if (s.m == 1) {
+                // range/mod.rs:198-226 + wip.rs:254-295
+                const F esq = fe_sqr(e);
+                head1 = e;
+                head2 = esq;
+                sh.cG() = fe_mul(fe_neg(z), esq);
+                kG = fe_mul(fe_mul(rp, e), y);
+                kH = fe_mul(sp, e);
+                cH = esq;
+                const F y_n1 = fe_pow_u64(y, (uint64_t)s.n + 1);
+                F gc = F::zero();  // sum_{i<n} y^{i+1}
+                {
+                    F cur = y;
+                    for (uint32_t i = 0; i < s.n; i++) {
+                        gc = fe_add(gc, cur);
+                        cur = fe_mul(cur, y);
+                    }
+                }
+                gc = fe_mul(gc, fe_sub(z, zsq));
+                const F two = fe_from_u32<P>(2);
+                const F t = fe_sub(fe_pow_u64(two, s.n), F::one());
+                gc = fe_sub(gc, fe_mul(fe_mul(t, y_n1), z));
+                g_exp = fe_add(fe_mul(fe_mul(fe_neg(rp), y), sp), fe_mul(gc, esq));
+                h_exp = fe_neg(dp);
+                lr_mul = esq;
+                sh.pz[0] = F::one();
+                fe_to_canonical(fe_mul(y_n1, esq), wv);  // V_exp
+                st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn) * 8, wv);
+            } else {
+                // range/mod.rs:417-477
+                const F einv2 = fe_sqr(einv);  // == (e^2)^-1
+                head1 = einv;
+                head2 = einv2;
+                sh.cG() = fe_neg(z);
+                kG = fe_mul(fe_mul(rp, einv), y);
+                kH = fe_mul(sp, einv);
+                cH = F::one();
+                const F y_mn1 = fe_pow_u64(y, (uint64_t)mn + 1);
+                const F sum_y = sum_of_powers<P>(y, mn, true);
+                const F sum_2 = sum_of_powers<P>(fe_from_u32<P>(2), s.n, false);
+                const F sum_z = sum_of_powers<P>(zsq, s.m, true);
+                const F t1 = fe_mul(fe_mul(fe_mul(fe_neg(rp), sp), y), einv2);
+                const F t2 = fe_sub(fe_mul(sum_y, fe_sub(z, zsq)), fe_mul(fe_mul(fe_mul(y_mn1, z), sum_2), sum_z));
+                g_exp = fe_add(t1, t2);
+                h_exp = fe_mul(fe_neg(dp), einv2);
+                lr_mul = F::one();
+                F cur = zsq;
+                for (uint32_t j = 0; j < s.m; j++) {  // power_of_z and V_exp
+                    sh.pz[j] = cur;
+                    fe_to_canonical(fe_mul(cur, y_mn1), wv);
+                    st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn + j) * 8, wv);
+                    cur = fe_mul(cur, zsq);
                 }
             }
-            gc = fe_mul(gc, fe_sub(z, zsq));
-            F two = fe_from_u32<P>(2);
-            F t = fe_sub(fe_pow_u64(two, s.n), F::one());
-            gc = fe_sub(gc, fe_mul(fe_mul(t, y_n1), z));
-            g_exp = fe_add(fe_mul(fe_mul(fe_neg(rp), y), sp), fe_mul(gc, esq));
-            h_exp = fe_neg(dp);
-            lr_mul = esq;
-            sh_pz[0] = fe_mul(y_n1, esq);  // V_exp
-        } else {
-            // range/mod.rs:417-477
-            const F einv2 = fe_sqr(einv);  // == (e^2)^-1
-            head1 = einv;
-            head2 = einv2;
-            sh_cG = fe_neg(z);
-            sh_kG = fe_mul(fe_mul(rp, einv), y);
-            sh_kH = fe_mul(sp, einv);
-            sh_cH = F::one();
-            const F y_mn1 = fe_pow_u64(y, (uint64_t)mn + 1);
-            const F sum_y = sum_of_powers<P>(y, mn, true);
-            const F sum_2 = sum_of_powers<P>(fe_from_u32<P>(2), s.n, false);
-            const F sum_z = sum_of_powers<P>(zsq, s.m, true);
-            F t1 = fe_mul(fe_mul(fe_mul(fe_neg(rp), sp), y), einv2);
-            F t2 = fe_sub(fe_mul(sum_y, fe_sub(z, zsq)), fe_mul(fe_mul(fe_mul(y_mn1, z), sum_2), sum_z));
-            g_exp = fe_add(t1, t2);
-            h_exp = fe_mul(fe_neg(dp), einv2);
-            lr_mul = F::one();
-            F cur = zsq;
-            for (uint32_t j = 0; j < s.m; j++) {  // power_of_z and V_exp
-                sh_pz[j] = cur;
-                uint32_t wv[8];
-                fe_to_canonical(fe_mul(cur, y_mn1), wv);
-                st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn + j) * 8, wv);
-                cur = fe_mul(cur, zsq);
+            sh.kGa() = fe_mul(kG, allinv);
+            sh.kHa() = fe_mul(kH, allinv);
+            sh.hmul() = cH;
+            sh.zc() = fe_mul(z, cH);
+            fe_to_canonical(F::one(), wv);
+            st_words<8>(o + 0, wv);
+            fe_to_canonical(head1, wv);
+            st_words<8>(o + 8, wv);
+            fe_to_canonical(head2, wv);
+            st_words<8>(o + 16, wv);
+            fe_to_canonical(g_exp, wv);
+            st_words<8>(o + 24, wv);
+            fe_to_canonical(h_exp, wv);
+            st_words<8>(o + 32, wv);
+            for (uint32_t j = 0; j < k; j++) {
+                fe_to_canonical(fe_mul(sh.chsq[j], lr_mul), wv);
+                st_words<8>(o + (size_t)(5 + j) * 8, wv);
+                fe_to_canonical(fe_mul(sh.chinvsq[j], lr_mul), wv);
+                st_words<8>(o + (size_t)(5 + k + j) * 8, wv);
             }
         }
-        uint32_t wv[8];
-        fe_to_canonical(F::one(), wv);
-        st_words<8>(o + 0, wv);
-        fe_to_canonical(head1, wv);
-        st_words<8>(o + 8, wv);
-        fe_to_canonical(head2, wv);
-        st_words<8>(o + 16, wv);
-        fe_to_canonical(g_exp, wv);
-        st_words<8>(o + 24, wv);
-        fe_to_canonical(h_exp, wv);
-        st_words<8>(o + 32, wv);
-        for (uint32_t j = 0; j < k; j++) {
-            fe_to_canonical(fe_mul(sh_chsq[j], lr_mul), wv);
-            st_words<8>(o + (size_t)(5 + j) * 8, wv);
-            fe_to_canonical(fe_mul(fe_sqr(sh_chinv[j]), lr_mul), wv);
-            st_words<8>(o + (size_t)(5 + k + j) * 8, wv);
-        }
-        if (s.m == 1) {
-            fe_to_canonical(sh_pz[0], wv);
-            st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn) * 8, wv);
-        }
-    } else if (tid == 64) {
-        uint32_t w[8];
-        ld_words<8>(ch + 0, w);
-        F y = fe_from_canonical<P>(w);
-        F yi = sh_yinv;
-        for (uint32_t bnum = 0; bnum <= k; bnum++) {  // y^(2^b), y^-(2^b)
-            sh_ypw[bnum] = y;
-            sh_yipw[bnum] = yi;
-            y = fe_sqr(y);
-            yi = fe_sqr(yi);
+    } else if (tid >= 64 && tid < 64 + VS_PB) {
+        const uint32_t q = tid - 64;
+        const size_t b = (size_t)blockIdx.x * VS_PB + q;
+        if (b < count) {
+            VsShared<F> sh = proof_lds(q);
+            uint32_t w[8];
+            ld_words<8>(challenges + (size_t)ch_stride * b, w);
+            F y = fe_from_canonical<P>(w);
+            F yi = sh.yinv();
+            for (uint32_t bnum = 0; bnum <= k; bnum++) {  // y^(2^b), y^-(2^b)
+                sh.ypw[bnum] = y;
+                sh.yipw[bnum] = yi;
+                y = fe_sqr(y);
+                yi = fe_sqr(yi);
+            }
         }
     }
     __syncthreads();
 
-    // phase C: G_exp[i], H_exp[i]
-    const F allinv = sh_allinv, cG = sh_cG, kG = sh_kG, kH = sh_kH, cH = sh_cH, z = sh_z;
-    for (uint32_t i = tid; i < mn; i += blockDim.x) {
-        // s_vec[i] = allinv * prod_{bit b of i set} e^2_{k-1-b}   (wip.rs:372-380 unrolled);
-        // s_vec[mn-1-i] takes the complementary bits
-        F sp_i = allinv, sr_i = allinv;
-        for (uint32_t bnum = 0; bnum < k; bnum++) {
-            const F u = sh_chsq[k - 1 - bnum];
-            if ((i >> bnum) & 1u) sp_i = fe_mul(sp_i, u);
-            else sr_i = fe_mul(sr_i, u);
+    // ---- phase B': low-bit tables, lane l < CH of each proof -----------------------------------------
+    const uint32_t q = tid / 64, lane = tid % 64;
+    const size_t b = (size_t)blockIdx.x * VS_PB + q;
+    const bool active = b < count;
+    VsShared<F> sh = proof_lds(q);
+    if (active && lane < CH) {
+        F slo = F::one(), sclo = F::one(), yl = F::one();
+        for (uint32_t bnum = 0; bnum < cb; bnum++) {
+            const F u = sh.chsq[k - 1 - bnum];
+            if ((lane >> bnum) & 1u) {
+                slo = fe_mul(slo, u);
+                yl = fe_mul(yl, sh.yipw[bnum]);
+            } else {
+                sclo = fe_mul(sclo, u);
+            }
         }
-        F yip = F::one(), yp = F::one();  // y^-(i+1), y^(mn-i)
-        const uint32_t e1 = i + 1, e2 = mn - i;
+        sh.sy_lo[lane] = fe_mul(slo, yl);                // prod e^2 * y^-l
+        sh.sc_lo[lane] = sclo;
+        sh.t_lo[lane] = fe_mul(sh_p2[lane], yl);         // 2^l * y^-l   (l < CH <= n)
+    }
+    __syncthreads();
+
+    // ---- phase C --------------------------------------------------------------------------------------
+    if (!active) return;
+    const uint32_t i0 = lane * CH;
+    if (i0 >= mn) return;
+    uint32_t* o = out + b * (size_t)s.N * 8;
+    F a_hi = sh.kGa(), c_hi = sh.kHa();
+    for (uint32_t bnum = cb; bnum < k; bnum++) {
+        const F u = sh.chsq[k - 1 - bnum];
+        if ((i0 >> bnum) & 1u) a_hi = fe_mul(a_hi, u);
+        else c_hi = fe_mul(c_hi, u);
+    }
+    F yip = F::one(), yp = F::one();  // y^-(i0+1), y^(mn-i0)
+    {
+        const uint32_t e1 = i0 + 1, e2 = mn - i0;
         for (uint32_t bnum = 0; bnum <= k; bnum++) {
-            if ((e1 >> bnum) & 1u) yip = fe_mul(yip, sh_yipw[bnum]);
-            if ((e2 >> bnum) & 1u) yp = fe_mul(yp, sh_ypw[bnum]);
+            if ((e1 >> bnum) & 1u) yip = fe_mul(yip, sh.yipw[bnum]);
+            if ((e2 >> bnum) & 1u) yp = fe_mul(yp, sh.ypw[bnum]);
         }
-        // G_exp = cG - s_i * y^-(i+1) * kG        (range/mod.rs:456-459 ; wip.rs:273-280)
-        F ge = fe_sub(cG, fe_mul(fe_mul(sp_i, yip), kG));
-        // H_exp = -kH * s_{mn-1-i} + (d_i * y^(mn-i) + z) * cH     (range/mod.rs:461-465 ; wip.rs:282-286)
-        F d = sh_p2[i % s.n];
-        if (s.m != 1) d = fe_mul(d, sh_pz[i / s.n]);
-        F he = fe_add(fe_mul(d, yp), z);
-        if (s.m == 1) he = fe_mul(he, cH);
-        he = fe_sub(he, fe_mul(kH, sr_i));
+    }
+    a_hi = fe_mul(a_hi, yip);
+    F b_hi = fe_mul(fe_mul(yp, sh_p2[i0 % s.n]), sh.hmul());
+    if (s.m != 1) b_hi = fe_mul(b_hi, sh.pz[i0 / s.n]);
+    const F cG = sh.cG(), zc = sh.zc();
+    for (uint32_t l = 0; l < CH; l++) {
+        const uint32_t i = i0 + l;
+        const F ge = fe_sub(cG, fe_mul(a_hi, sh.sy_lo[l]));
+        const F he = fe_sub(fe_add(fe_mul(b_hi, sh.t_lo[l]), zc), fe_mul(c_hi, sh.sc_lo[l]));
         uint32_t wv[8];
         fe_to_canonical(ge, wv);
         st_words<8>(o + (size_t)(5 + 2 * k + i) * 8, wv);

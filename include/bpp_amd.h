@@ -134,6 +134,22 @@ int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *
                      size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
                      void *stream);
 
+/* ---- combined batch check ("final multiscalar check") -- an engine mode, NOT a reference code path ----
+ * One random linear combination of the batch's verification MulVecs, sum_p w_p * M_p == identity, with
+ * w_p = 128-bit odd values from SplitMix64(seed, p) (csrc/combined.hpp): the fixed generators collapse
+ * to one fixed-base MulVec, the proof-carried points form one bucket-method MulVec.  An all-valid batch
+ * always passes; a batch holding an invalid proof fails except with probability ~2^-128 over the weights,
+ * and the caller then runs bpp_verifier_run for the exact per-proof verdicts of the reference.
+ *   d_out_partial: bpp_verifier_partial_bytes() bytes -- this call's weighted sum (opaque jacobian image);
+ *                  ranks exchange these once (RCCL all-gather) and bpp_verifier_sum_partials adds them
+ *   d_ok         : one uint32_t, 0 iff the partial is the identity and every proof point was valid */
+size_t bpp_verifier_partial_bytes(const bpp_verifier *v);
+size_t bpp_verifier_combined_workspace_bytes(const bpp_verifier *v, size_t count);
+int bpp_verifier_run_combined(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                              const uint64_t *d_challenges, uint64_t seed, void *d_out_partial, uint32_t *d_ok,
+                              void *d_workspace, size_t workspace_bytes, void *stream);
+int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n, uint32_t *d_ok, void *stream);
+
 /* Per-stage timing with HIP events recorded on the caller's stream around each kernel of a pass
  * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant], 3 proof-point MSM,
  * 4 finalize).  bpp_verifier_profile averages over the passes recorded since profiling was switched on

@@ -41,3 +41,19 @@ def run_verifier_device(torch, bv, records, scalars, want_scalars=True, want_res
     os_ = d_os.cpu().numpy().view(np.uint64) if d_os is not None else None
     or_ = d_or.cpu().numpy().view(np.uint64) if d_or is not None else None
     return ok, os_, or_
+
+
+def run_combined_device(torch, bv, records, scalars, seed=12345):
+    """Combined batch check on device -> (ok_flag, partial bytes as numpy uint8)"""
+    dev = torch.device("cuda:0")
+    count = records.shape[0]
+    d_pts = torch.from_numpy(np.ascontiguousarray(records).view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(np.ascontiguousarray(scalars).view(np.int64)).to(dev)
+    d_ok = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    d_part = torch.zeros(bv.partial_bytes(), dtype=torch.uint8, device=dev)
+    wsb = bv.combined_workspace_bytes(count)
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    bv.run_combined_device(d_pts.data_ptr(), d_sc.data_ptr(), count, seed, d_part.data_ptr(), d_ok.data_ptr(),
+                           d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return int(d_ok.item()), d_part.cpu().numpy()

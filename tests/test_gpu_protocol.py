@@ -7,7 +7,7 @@ import pytest
 
 import oracle as O
 import pyref as P
-from gpu_util import need_gpu, hexpt, run_verifier_device
+from gpu_util import need_gpu, hexpt, run_verifier_device, run_combined_device
 
 pytestmark = pytest.mark.gpu
 
@@ -198,3 +198,80 @@ def test_window_sizes_agree(golden):
         bv.close()
     for r in results[1:]:
         assert np.array_equal(r, results[0])
+
+
+@pytest.mark.parametrize("cname,n,vals,gams,c", [
+    ("bls12_381", 8, [200, 5], [3, 7], 5),
+    ("secp256k1", 8, [77], [9], 6),
+])
+def test_combined_check_agrees_with_per_proof_verdicts(cname, n, vals, gams, c):
+    """Combined batch check (engine mode, not a reference path): passes iff every per-proof verdict of the
+    reference-exact path is Ok; different seeds agree; partials of two half-batches add up to the whole."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    cid = CID[cname]
+    m = len(vals)
+    a = B.Arith.init(cid)
+    opk = O.PublicKey(cid, n * m)
+    pk = B.PublicKey.from_points(a, opk.gh, opk.G, opk.H)
+    bv = B.BatchVerifier(pk, n, m, window_bits=c)
+    good = []
+    for t in range(6):
+        pts, sc, V = O.range_prove(opk, n, [(v * (t + 3) + t) % (1 << n) for v in vals], [g + 5 * t for g in gams])
+        good.append((np.concatenate([pts, V]), sc))
+    recs = np.stack([g[0] for g in good])
+    scs = np.stack([g[1] for g in good])
+    assert bv.verify_wire(recs, scs).tolist() == [0] * 6
+    for seed in (1, 2, 0xDEADBEEF):
+        ok, _ = run_combined_device(torch, bv, recs, scs, seed)
+        assert ok == 0
+    for victim in (0, 3, 5):
+        bad = scs.copy()
+        bad[victim, 1, 0] ^= 1
+        assert bv.verify_wire(recs, bad).tolist() == [1 if i == victim else 0 for i in range(6)]
+        for seed in (1, 99):
+            ok, _ = run_combined_device(torch, bv, recs, bad, seed)
+            assert ok == 1
+    # a moved proof point and an off-curve point are caught too
+    r2 = recs.copy()
+    r2[2, 3] = recs[2, 4] if recs.shape[1] > 5 else opk.gh[1]
+    assert run_combined_device(torch, bv, r2, scs, 7)[0] == 1
+    r3 = recs.copy()
+    r3[4, 0, 0] ^= 1
+    assert run_combined_device(torch, bv, r3, scs, 7)[0] == 1
+    # multi-rank combine: the partials of two shards of a batch holding one bad proof do not cancel, while
+    # the partials of two all-valid shards are both the identity
+    dev = torch.device("cuda:0")
+    bad = scs.copy()
+    bad[1, 0, 0] ^= 2
+    parts = []
+    for lo, hi, seed in ((0, 3, 11), (3, 6, 12)):
+        ok, part = run_combined_device(torch, bv, recs[lo:hi], bad[lo:hi], seed)
+        parts.append(part)
+    d_parts = torch.from_numpy(np.concatenate(parts)).to(dev)
+    d_ok = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    bv.sum_partials_device(d_parts.data_ptr(), 2, d_ok.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_ok.item()) == 1
+    parts = [run_combined_device(torch, bv, recs[lo:hi], scs[lo:hi], seed)[1] for lo, hi, seed in ((0, 3, 11), (3, 6, 12))]
+    d_parts = torch.from_numpy(np.concatenate(parts)).to(dev)
+    bv.sum_partials_device(d_parts.data_ptr(), 2, d_ok.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_ok.item()) == 0
+
+
+def test_combined_check_reference_size(golden):
+    """(64,16): combined check over a batch built from the golden proof (valid) and a tampered copy."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    case = golden("protocol_full_bls12_381.json")[2]
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, 1024)
+    bv = B.BatchVerifier(pk, 64, 16, window_bits=9)
+    pts, V, sc = golden_record(0, case)
+    rec = np.concatenate([pts, V])
+    recs = np.stack([rec] * 120)
+    scs = np.stack([sc] * 120)
+    assert run_combined_device(torch, bv, recs, scs, 5)[0] == 0
+    scs[77, 2, 1] ^= 1
+    assert run_combined_device(torch, bv, recs, scs, 5)[0] == 1
