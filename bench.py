@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(8, cores); -1 disables the CPU leg")
     ap.add_argument("--cpu-per-thread", type=int, default=2)
+    ap.add_argument("--combined-steps", type=int, default=-1,
+                    help="extra (separately timed) steps of the combined batch check; -1 = same as --steps, 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -171,6 +173,47 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- secondary, separately timed: the combined batch check (engine mode, not the reference's per-proof
+    # semantics; see include/bpp_amd.h).  One weighted MulVec per rank, partials exchanged once per step.
+    comb = None
+    csteps = args.steps if args.combined_steps < 0 else args.combined_steps
+    if csteps > 0:
+        cwsb = bv.combined_workspace_bytes(Bsz)
+        d_cws = torch.empty(cwsb, dtype=torch.uint8, device=dev)
+        pbytes = bv.partial_bytes()
+        d_part = torch.zeros(pbytes, dtype=torch.uint8, device=dev)
+        d_all = torch.zeros(world * pbytes, dtype=torch.uint8, device=dev)
+        d_cok = torch.full((1,), 7, dtype=torch.int32, device=dev)
+
+        def cstep(i):
+            bv.run_combined_device(d_pts.data_ptr(), d_sc.data_ptr(), Bsz, 0xB0117E7 + 1000 * i + rank, d_part.data_ptr(),
+                                   d_cok.data_ptr(), d_cws.data_ptr(), cwsb, stream)
+            if dist is not None:
+                dist.all_gather_into_tensor(d_all, d_part)      # the single exchange: one 144-byte partial per rank
+                bv.sum_partials_device(d_all.data_ptr(), world, d_cok.data_ptr(), stream)
+
+        cstep(0)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for i in range(csteps):
+            cstep(i + 1)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        cdt = time.perf_counter() - tc0
+        assert int(d_cok.item()) == 0, "combined check rejected an all-valid batch"
+        if dist is not None:
+            tmax = torch.tensor([cdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            cdt = float(tmax.item())
+        comb = {"value": world * Bsz * csteps / cdt, "unit": "verifies/s", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                "note": "random-linear-combination batch check (SplitMix64 weights): batch verdict only, NOT the "
+                        "reference's per-proof verdicts; reported beside `value`, never as it"}
+
     if rank == 0:
         N_msm = bv.msm_len
         NF = 2 * n * m + 2
@@ -204,6 +247,7 @@ def main():
                          "blocks_per_proof": bpp_,
                          "note": "integer-ALU bound, not HBM bound: see DESIGN.md (ALU roofline in profiles/)"},
             "stage_ms": stage_ms,
+            "combined_check": comb,
             "setup_s": {"prove_%d" % D: t_prove, "tables": t_tables},
         }
         thr = args.cpu_threads
