@@ -395,6 +395,30 @@ def _verifier_sum_partials_device(self, d_partials: int, n: int, d_ok: int, stre
           "bpp_verifier_sum_partials")
 
 
+def _engine_prove_batch(self, values, gammas):
+    """RangeProof::prove + RangeProver::commit for `count` provers sharing this engine's (pk, n, m).
+    values: (count, m) ints < 2^64 ; gammas: (count, m) scalars (ints or (count, m, 4) uint64).
+    Returns (points (count, 3+2k, PW), scalars (count, 3, 4), V (count, m, PW)) in wire format --
+    bit-identical to RangeProof.prove / RangeProver.commit one by one."""
+    vals = np.ascontiguousarray(np.asarray(values, dtype=np.uint64).reshape(-1, self.m))
+    count = vals.shape[0]
+    if isinstance(gammas, np.ndarray) and gammas.dtype == np.uint64 and gammas.ndim == 3:
+        gm = np.ascontiguousarray(gammas)
+    else:
+        gm = np.zeros((count, self.m, 4), dtype=np.uint64)
+        for i, row in enumerate(gammas):
+            for j, g in enumerate(row):
+                gm[i, j] = scalar_to_wire(g)
+    PW = self.arith.PW
+    pts = np.zeros((count, 3 + 2 * self.k, PW), dtype=np.uint64)
+    sc = np.zeros((count, 3, 4), dtype=np.uint64)
+    V = np.zeros((count, self.m, PW), dtype=np.uint64)
+    check(_lib.lib().bpp_range_prove_batch(self.handle, _ptr(vals), _ptr(gm), count, _ptr(pts), _ptr(sc), _ptr(V)),
+          "bpp_range_prove_batch")
+    return pts, sc, V
+
+
+BatchVerifier.prove_batch = _engine_prove_batch
 BatchVerifier.partial_bytes = _verifier_partial_bytes
 BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device

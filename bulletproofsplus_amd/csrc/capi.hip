@@ -137,6 +137,16 @@ extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const
     });
 }
 
+extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, const uint64_t* gamma, size_t count,
+                                     uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+    if (!engine || !v || !gamma || !out_points || !out_scalars) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(engine->ctx.device));
+    return dispatch(engine->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V);
+    });
+}
+
 // ---- combined batch check ------------------------------------------------------------------------------
 extern "C" size_t bpp_verifier_partial_bytes(const bpp_verifier* v) {
     if (!v) return 0;

@@ -4,6 +4,7 @@
 #include "combined.hpp"
 #include "host_util.hpp"
 #include "pippenger.hpp"
+#include "prover_batch.hpp"
 
 // stages of one pass, in launch order (bpp_verifier_profile reports one duration per stage)
 enum { BPP_STAGE_FROM_WIRE = 0, BPP_STAGE_SCALARS, BPP_STAGE_FIXED_MSM, BPP_STAGE_VAR_MSM, BPP_STAGE_FINALIZE,
@@ -148,8 +149,8 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(bpp_, (unsigned)count), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
-                           s, w_sc, v->table.u32(), w_fp);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
+                           s, w_sc, v->table.u32(), w_fp, bpp_);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_var_msm<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_sc, w_pts, w_vt,
                            w_vp, npts);
@@ -221,12 +222,72 @@ struct VerifyImpl {
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks, 1), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st, s,
-                           w_cs, v->table.u32(), w_fp);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st, s,
+                           w_cs, v->table.u32(), w_fp, L.fixed_blocks);
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
         HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
         HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+
+    // ---- batched prover (prover_batch.hpp): host buffers in, host buffers out -------------------------
+    static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
+                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+        const VerifyShape& s = v->s;
+        const uint32_t k = s.k, m = s.m, mn = s.mn;
+        const uint32_t nvp = pb_num_vps(k, m);
+        ProverConsts pc;
+        pc.alpha = m == 1 ? 7 : 33;   // range/mod.rs:94 / :256
+        pc.d_L = 4;                   // wip.rs:94
+        pc.d_R = 5;                   // wip.rs:95
+        pc.r = 33;                    // wip.rs:175
+        pc.s = 44;
+        pc.delta = 88;
+        pc.eta = 123;
+        const size_t chunk_max = std::max<size_t>(1, std::min<size_t>(1024, ((size_t)6 << 30) / ((size_t)nvp * s.N * 32)));
+        hipStream_t st = nullptr;
+        for (size_t base = 0; base < count; base += chunk_max) {
+            const size_t cnt = std::min(chunk_max, count - base);
+            const size_t nv_total = cnt * nvp;
+            const unsigned per = blocks_per_proof(s, nv_total);
+            DevBuf d_val, d_gam, d_a, d_b, d_cG, d_cH, d_pwy, d_con, d_vps, d_part, d_pts, d_V, d_sc;
+            HIPCHK(d_val.alloc(cnt * m * 8));
+            HIPCHK(hipMemcpyAsync(d_val.p, values + base * m, cnt * m * 8, hipMemcpyHostToDevice, st));
+            int rc = upload_scalars<C>(gammas + base * m * 4, cnt * m, d_gam, st);
+            if (rc) return rc;
+            const size_t vec = cnt * (size_t)mn * 32;
+            HIPCHK(d_a.alloc(vec));
+            HIPCHK(d_b.alloc(vec));
+            HIPCHK(d_cG.alloc(vec));
+            HIPCHK(d_cH.alloc(vec));
+            HIPCHK(d_pwy.alloc(vec));
+            HIPCHK(d_con.alloc(cnt * (size_t)pb_consts_elems(k) * 32));
+            HIPCHK(d_vps.alloc(nv_total * (size_t)s.N * 32));
+            HIPCHK(d_part.alloc(nv_total * per * 3 * N * 4));
+            HIPCHK(d_pts.alloc(cnt * (size_t)(3 + 2 * k) * WW * 4));
+            HIPCHK(d_V.alloc(cnt * (size_t)m * WW * 4));
+            HIPCHK(d_sc.alloc(cnt * 3 * 32));
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc,
+                               static_cast<const uint64_t*>(d_val.p), d_gam.u32(), v->challenges.u32(), 0u, d_a.u32(),
+                               d_b.u32(), d_cG.u32(), d_cH.u32(), d_pwy.u32(), d_con.u32(), d_vps.u32());
+            for (uint32_t t = 0; t < k; t++)
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, d_a.u32(), d_b.u32(),
+                                   d_cG.u32(), d_cH.u32(), d_pwy.u32(), d_con.u32(), d_vps.u32());
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
+                               d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
+            hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
+                               FIXED_BLOCK * 3 * N * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per);
+            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
+                               d_pts.u32(), d_V.u32(), nv_total);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(out_points + base * (3 + 2 * k) * PW, d_pts.p, cnt * (size_t)(3 + 2 * k) * WW * 4,
+                                  hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(out_scalars + base * 12, d_sc.p, cnt * 96, hipMemcpyDeviceToHost, st));
+            if (out_V)
+                HIPCHK(hipMemcpyAsync(out_V + base * m * PW, d_V.p, cnt * (size_t)m * WW * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
         return BPP_OK;
     }
 

@@ -576,19 +576,21 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // Fixed-generator part: for proof b = blockIdx.y, sum_f scalar_f * F_f through the window tables.
 // scalar + bias -> W unsigned windows -> signed digits in [-half, half) -> one table gather and one mixed
 // addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
-// that.  partials: [count][gridDim.x] jacobians.
+// that.  partials: [count][per] jacobians.
 template <class C>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
-                            const uint32_t* __restrict__ table, uint32_t* __restrict__ partials) {
+                            const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per) {
     constexpr int N = C::Fp::N;
     extern __shared__ __align__(16) uint32_t lds[];
-    const size_t b = blockIdx.y;
+    // flat grid: block = proof * per + part   (`per` blocks share one proof's generators)
+    const size_t b = blockIdx.x / per;
+    const uint32_t part = blockIdx.x % per;
     const uint32_t* sc = scalars + b * (size_t)s.N * 8;
     const uint32_t mask = (1u << s.c) - 1u;
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t stride = per * blockDim.x;
     Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
     // software pipeline: the table entry of step t+1 is gathered while the mixed addition of step t runs
-    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t f = part * blockDim.x + threadIdx.x;
     uint32_t j = s.W;  // forces the first scalar load
     uint32_t w[10];
     bool have = false;   // a prefetched entry is pending
@@ -636,7 +638,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
         acc = xyzz_madd(acc, cur);
     }
     Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (b * gridDim.x + blockIdx.x) * 3 * N, sum);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)blockIdx.x * 3 * N, sum);
 }
 
 // Proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments.  One lane per

@@ -134,6 +134,16 @@ int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *
                      size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
                      void *stream);
 
+/* RangeProof::prove for `count` independent provers that share (pk, n, m) -- and RangeProver::commit for
+ * their values -- in one device-resident pass (csrc/prover_batch.hpp): the folding rounds of
+ * src/weighted_inner_product_proof.rs:79-172 fold only scalars, every L, R, A, B is a MulVec over the
+ * original generators through the engine's window tables.  Output is bit-identical to bpp_range_prove.
+ *   v: count x m uint64_t ; gamma: count x m scalars
+ *   out_points : count x (3 + 2k) points [A, wip.A, wip.B, L.., R..] ; out_scalars: count x 3 scalars
+ *   out_V      : count x m commitments (may be NULL).  Host pointers. */
+int bpp_range_prove_batch(bpp_verifier *engine, const uint64_t *v, const uint64_t *gamma, size_t count,
+                          uint64_t *out_points, uint64_t *out_scalars, uint64_t *out_V);
+
 /* ---- combined batch check ("final multiscalar check") -- an engine mode, NOT a reference code path ----
  * One random linear combination of the batch's verification MulVecs, sum_p w_p * M_p == identity, with
  * w_p = 128-bit odd values from SplitMix64(seed, p) (csrc/combined.hpp): the fixed generators collapse

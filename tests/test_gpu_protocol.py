@@ -275,3 +275,58 @@ def test_combined_check_reference_size(golden):
     assert run_combined_device(torch, bv, recs, scs, 5)[0] == 0
     scs[77, 2, 1] ^= 1
     assert run_combined_device(torch, bv, recs, scs, 5)[0] == 1
+
+
+@pytest.mark.parametrize("cname,n,m,c", [("bls12_381", 8, 2, 5), ("secp256k1", 8, 1, 4), ("bls12_381", 4, 4, 6)])
+def test_prove_batch_matches_oracle_small(cname, n, m, c):
+    """Batched device prover (scalar folding + window tables) == oracle prover, bit for bit, and its
+    proofs verify (and out-of-range values fail) on the batch verifier."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    cid = CID[cname]
+    a = B.Arith.init(cid)
+    opk = O.PublicKey(cid, n * m)
+    pk = B.PublicKey.from_points(a, opk.gh, opk.G, opk.H)
+    eng = B.BatchVerifier(pk, n, m, window_bits=c)
+    r = P.CURVES[cname]["r"]
+    vals = [[(37 * i + 11 * j + 5) % (1 << n) for j in range(m)] for i in range(9)]
+    vals[3][0] += 1 << n                       # out of range
+    vals[5][m - 1] = (1 << 40) + 3             # truncated by `v as i32` in commit, bits beyond n set
+    gams = [[(i * 1000003 + j * 7919 + 1) % r if i != 4 else r - 1 - j for j in range(m)] for i in range(9)]
+    pts, sc, V = eng.prove_batch(vals, gams)
+    exp_ok = []
+    for i in range(9):
+        opts, osc, oV = O.range_prove(opk, n, vals[i], gams[i])
+        assert np.array_equal(pts[i], opts), i
+        assert np.array_equal(sc[i], osc), i
+        assert np.array_equal(V[i], oV), i
+        exp_ok.append(O.range_verify(opk, n, m, opts, osc, oV))
+    recs = np.concatenate([pts, V], axis=1)
+    assert eng.verify_wire(recs, sc).tolist() == exp_ok
+    assert exp_ok[0] == 0 and exp_ok[3] == 1
+
+
+def test_prove_batch_reference_sizes(golden):
+    """(64,2) main.rs, (32,1) and (64,16): batched prover == golden proofs; a distinct batch verifies."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init("bls12_381")
+    for case, c in zip(golden("protocol_full_bls12_381.json"), (9, 8, 10)):
+        n, m = case["n"], case["m"]
+        pk = B.PublicKey.new(a, n * m)
+        eng = B.BatchVerifier(pk, n, m, window_bits=c)
+        gpts, gV, gsc = golden_record(0, case)
+        vals = [case["values"], [(v * 3 + 1) % (1 << 31) for v in case["values"]]]
+        gams = [case["gammas"], [g + 9 for g in case["gammas"]]]
+        pts, sc, V = eng.prove_batch(vals, gams)
+        assert np.array_equal(pts[0], gpts) and np.array_equal(sc[0], gsc) and np.array_equal(V[0], gV)
+        recs = np.concatenate([pts, V], axis=1)
+        assert eng.verify_wire(recs, sc).tolist() == [0, 0]
+        # the single-proof API gives the same second proof
+        pr = B.RangeProver.new()
+        for v, g in zip(vals[1], gams[1]):
+            pr.commit(pk, v, g)
+        if n * m <= 128:
+            proof = B.RangeProof.prove(pk, n, pr)
+            assert np.array_equal(proof.points_wire(), pts[1]) and np.array_equal(proof.scalars_wire(), sc[1])
+        eng.close()
