@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) k_comb_verdict(const uint32_t* __restrict
     for (size_t p = threadIdx.x; p < count; p += blockDim.x) anybad |= (bad[p] != 0);
     anybad = __syncthreads_or(anybad);
     if (threadIdx.x == 0) {
-        Jac<C> acc = jac_ldg<C>(partial);
+        Jac<C> acc = jac_ldg<C>(partial + threadIdx.x);
         ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
     }
 }
@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __rest
                                                           uint32_t* __restrict__ ok, uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t lane_zero;  // keeps the wave-uniform chain on the vector unit (see k_pip_final)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    partials += lane_zero;
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < n; t++) acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * 3 * N));
     ok[0] = acc.is_inf() ? 0u : 1u;

@@ -12,11 +12,15 @@
 //                  returned value is the point's slot inside its bucket
 //   k_pip_scan     per window: exclusive prefix sum of the histogram (LDS, one block per window)
 //   k_pip_scatter  per (window, point): sorted[offset[bucket] + slot] = point index | sign
-//   k_pip_buckets  per (window, bucket): XYZZ running sum of its points (gathered from HBM)
+//   k_pip_buckets  per (window, bucket): XYZZ running sum of its points (gathered from HBM); buckets with
+//                  more than PIP_HEAVY points are deferred to
+//   k_pip_heavy / k_pip_heavy_fold   which split one bucket over PIP_SPLIT x 128 lanes
 //   k_pip_windows  per window: sum_k (k+1) * B_k  by per-thread running sums over bucket segments, a small
 //                  scalar multiplication for the segment offset, and an LDS tree over the block
 //   k_pip_final    Horner over the W window sums (c doublings between windows), written as a jacobian
 #pragma once
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace bpp {
@@ -130,18 +134,32 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipShape s, const uint32_t*
     sorted[(size_t)j * s.n + offsets[(size_t)j * s.half + b] + slots[(size_t)j * s.n + i]] = (i << 1) | (key & 1u);
 }
 
+// Buckets holding more than PIP_HEAVY points are not summed by one lane: they go to a list and are split
+// over PIP_SPLIT blocks of 128 lanes each (k_pip_heavy), then folded back (k_pip_heavy_fold).  This is not a
+// corner case: the top window of a scalar < 2^255 holds only a carry bit, so half of all points can land
+// in ONE bucket there.
+constexpr uint32_t PIP_HEAVY = 96;
+constexpr uint32_t PIP_WIN_BLOCK = 512;   // lanes per window in k_pip_windows (short segments: the kernel is latency bound)
+constexpr uint32_t PIP_SPLIT = 16;
+
 // one thread per (window, bucket): bucket sum as a jacobian in buckets[j][b]
 template <class C>
 __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32_t* __restrict__ points,
                                                         const uint32_t* __restrict__ sorted,
                                                         const uint32_t* __restrict__ offsets,
                                                         const uint32_t* __restrict__ counts,
-                                                        uint32_t* __restrict__ buckets) {
+                                                        uint32_t* __restrict__ buckets,
+                                                        uint32_t* __restrict__ heavy_list,
+                                                        uint32_t* __restrict__ heavy_count) {
     constexpr int N = C::Fp::N;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)s.W * s.half) return;
     const uint32_t j = (uint32_t)(gid / s.half);
     const uint32_t beg = offsets[gid], cnt = counts[gid];
+    if (cnt > PIP_HEAVY) {
+        heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)gid;
+        return;
+    }
     const uint32_t* row = sorted + (size_t)j * s.n;
     Xyzz<C> acc = xyzz_inf<C>();
     for (uint32_t t = 0; t < cnt; t++) {
@@ -153,11 +171,60 @@ __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32
     jac_stg<C>(buckets + gid * 3 * N, xyzz_to_jac(acc));
 }
 
+// grid (any, PIP_SPLIT): block (h, part) sums part `part` of heavy bucket heavy_list[h] with 128 lanes and an
+// LDS tree; heavy_parts[h][part] receives the jacobian
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_pip_heavy(PipShape s, const uint32_t* __restrict__ points,
+                                                      const uint32_t* __restrict__ sorted,
+                                                      const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ heavy_list,
+                                                      const uint32_t* __restrict__ heavy_count,
+                                                      uint32_t* __restrict__ heavy_parts) {
+    constexpr int N = C::Fp::N;
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t gid = heavy_list[h];
+        const uint32_t j = gid / s.half;
+        const uint32_t beg = offsets[gid], cnt = counts[gid];
+        const uint32_t per = (cnt + PIP_SPLIT - 1) / PIP_SPLIT;
+        const uint32_t lo = min(cnt, blockIdx.y * per), hi = min(cnt, lo + per);
+        const uint32_t* row = sorted + (size_t)j * s.n + beg;
+        Xyzz<C> acc = xyzz_inf<C>();
+        for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+            const uint32_t e = row[t];
+            Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
+            if (e & 1u) q.y = fe_neg(q.y);
+            acc = xyzz_madd(acc, q);
+        }
+        Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
+        if (threadIdx.x == 0) jac_stg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + blockIdx.y) * 3 * N, sum);
+        __syncthreads();
+    }
+}
+
+// one lane per heavy bucket: bucket = sum of its PIP_SPLIT parts
+template <class C>
+__global__ void __launch_bounds__(64) k_pip_heavy_fold(const uint32_t* __restrict__ heavy_list,
+                                                       const uint32_t* __restrict__ heavy_count,
+                                                       const uint32_t* __restrict__ heavy_parts,
+                                                       uint32_t* __restrict__ buckets) {
+    constexpr int N = C::Fp::N;
+    const uint32_t nheavy = *heavy_count;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheavy; h += gridDim.x * blockDim.x) {
+        Jac<C> acc = jac_inf<C>();
+        for (uint32_t t = 0; t < PIP_SPLIT; t++)
+            acc = jac_add(acc, jac_ldg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + t) * 3 * N));
+        jac_stg<C>(buckets + (size_t)heavy_list[h] * 3 * N, acc);
+    }
+}
+
 // one block per window: R_j = sum_b (b + 1) * B_b.  Thread t owns the segment [t*S, (t+1)*S) with
 // S = half / blockDim.x (>= 1): descending running sums give sum (b - lo + 1) B_b and sum B_b, the
 // segment offset lo is applied with a short double-and-add, an LDS tree adds the threads.
 template <class C>
-__global__ void __launch_bounds__(128, 2) k_pip_windows(PipShape s, const uint32_t* __restrict__ buckets,
+__global__ void __launch_bounds__(PIP_WIN_BLOCK) k_pip_windows(PipShape s, const uint32_t* __restrict__ buckets,
                                                         uint32_t* __restrict__ window_sums) {
     constexpr int N = C::Fp::N;
     extern __shared__ __align__(16) uint32_t lds[];
@@ -193,18 +260,25 @@ __global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __
                                                   uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    // Everything below depends only on kernel arguments, i.e. is wave-uniform, and hipcc would compile it
+    // to the SCALAR unit (s_mul_i32 / s_mul_hi_u32 / s_addc_u32: ~4 instructions per limb product).  An
+    // opaque per-lane zero in the addresses keeps the chain on the vector unit (v_mad_u64_u32).
+    uint32_t lane_zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+    window_sums += lane_zero;
     Jac<C> acc = jac_inf<C>();
     for (uint32_t j = s.W; j-- > 0;) {
         if (!acc.is_inf())
             for (uint32_t t = 0; t < s.c; t++) acc = jac_dbl(acc);
         acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)j * 3 * N));
     }
-    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + (size_t)t * 3 * N));
+    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + lane_zero + (size_t)t * 3 * N));
     jac_stg<C>(out, acc);
 }
 
 struct PipWorkspace {
-    size_t keys, slots, sorted, counts, offsets, buckets, wsums, total;
+    size_t keys, slots, sorted, counts, offsets, buckets, wsums, hlist, hcount, hparts, total;
+    size_t max_heavy;
 };
 template <class C>
 inline PipWorkspace pip_workspace(const PipShape& s) {
@@ -226,6 +300,14 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     o += al((size_t)s.W * s.half * 3 * N * 4);
     w.wsums = o;
     o += al((size_t)s.W * 3 * N * 4);
+    // a heavy bucket holds > PIP_HEAVY of the W * n sorted entries
+    w.max_heavy = std::min<size_t>((size_t)s.W * s.half, (size_t)s.W * s.n / PIP_HEAVY + 1);
+    w.hlist = o;
+    o += al(w.max_heavy * 4);
+    w.hcount = o;
+    o += al(4);
+    w.hparts = o;
+    o += al(w.max_heavy * PIP_SPLIT * 3 * N * 4);
     w.total = o;
     return w;
 }
@@ -243,15 +325,24 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     uint32_t* offsets = reinterpret_cast<uint32_t*>(d_ws + w.offsets);
     uint32_t* buckets = reinterpret_cast<uint32_t*>(d_ws + w.buckets);
     uint32_t* wsums = reinterpret_cast<uint32_t*>(d_ws + w.wsums);
+    uint32_t* hlist = reinterpret_cast<uint32_t*>(d_ws + w.hlist);
+    uint32_t* hcount = reinterpret_cast<uint32_t*>(d_ws + w.hcount);
+    uint32_t* hparts = reinterpret_cast<uint32_t*>(d_ws + w.hparts);
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)s.W * s.half * 4, st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(hcount, 0, 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pip_digits<C>, dim3((s.n + 255) / 256), dim3(256), 0, st, s, d_scalars, keys, slots, counts);
     hipLaunchKernelGGL(k_pip_scan<C>, dim3(s.W), dim3(1024), 0, st, s, counts, offsets);
     hipLaunchKernelGGL(k_pip_scatter<C>, dim3((s.n + 255) / 256, s.W), dim3(256), 0, st, s, keys, slots, offsets, sorted);
     const size_t nb = (size_t)s.W * s.half;
     hipLaunchKernelGGL(k_pip_buckets<C>, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, st, s, d_points, sorted,
-                       offsets, counts, buckets);
-    hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(128), 128 * 3 * N * 4, st, s, buckets, wsums);
+                       offsets, counts, buckets, hlist, hcount);
+    const unsigned hgrid = (unsigned)std::min<size_t>(w.max_heavy, 2048);
+    hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * 3 * N * 4, st, s, d_points, sorted,
+                       offsets, counts, hlist, hcount, hparts);
+    hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3((hgrid + 63) / 64), dim3(64), 0, st, hlist, hcount, hparts, buckets);
+    hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(PIP_WIN_BLOCK), PIP_WIN_BLOCK * 3 * N * 4, st, s, buckets, wsums);
     hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(64), 0, st, s, wsums, d_extra, n_extra, d_out);
     return hipGetLastError();
 }
