@@ -239,7 +239,7 @@ def main():
             "metric": "aggregated range-proof verifies/sec (n=%d,m=%d)" % (n, m),
             "value": value, "unit": "verifies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32x%d (30-bit limbs, %d-bit field)" % ((a.PW - 1) // 2 * 2 + 1, fp_bytes * 8 - (3 if args.curve == "bls12_381" else 0)),
+            "vs_baseline": None, "dtype": "u32 (30-bit limbs of a %d-bit prime field, v_mad_u64_u32)" % (381 if args.curve == "bls12_381" else 256),
             "data": "synthetic: %d distinct GPU-proved proofs per GPU in a batch of %d; reference constants as transcript" % (D, Bsz),
             "config": {"workload": "n=%d m=%d aggregated range-proof verify, %s, batch %d per GPU, per-proof verdicts" % (n, m, args.curve, Bsz),
                        "curve": args.curve, "msm_terms_per_verify": N_msm, "window_bits": args.window,

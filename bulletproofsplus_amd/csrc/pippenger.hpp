@@ -342,6 +342,10 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * 3 * N * 4, st, s, d_points, sorted,
                        offsets, counts, hlist, hcount, hparts);
     hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3((hgrid + 63) / 64), dim3(64), 0, st, hlist, hcount, hparts, buckets);
+    // 512 lanes x 144 B of LDS exceed the 64 KB default for dynamic LDS: opt in (160 KB per CU on gfx950)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pip_windows<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(PIP_WIN_BLOCK * 3 * N * 4));
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(PIP_WIN_BLOCK), PIP_WIN_BLOCK * 3 * N * 4, st, s, buckets, wsums);
     hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(64), 0, st, s, wsums, d_extra, n_extra, d_out);
     return hipGetLastError();
