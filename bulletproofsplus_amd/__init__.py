@@ -4,4 +4,4 @@ is the host-side mirror of the reference's API for that path.  No CPU fallback."
 
 from .api import (Arith, BatchVerifier, MulVec, ProofError, PublicKey, RangeProof, RangeProver,  # noqa: F401
                   VerificationError, WeightedInnerProductProof, msm_batch, msm_pippenger, proof_record)
-from ._lib import BLS12_381_G1, SECP256K1, CURVE_IDS, BppError  # noqa: F401
+from ._lib import BLS12_381_G1, SECP256K1, ED25519, CURVE_IDS, BppError  # noqa: F401

@@ -16,8 +16,9 @@ LIB_PATH = os.environ.get("BPP_AMD_LIB") or os.path.join(_HERE, "libbpp_amd.so")
 
 BLS12_381_G1 = 0
 SECP256K1 = 1
-CURVE_IDS = {"bls12_381": BLS12_381_G1, "secp256k1": SECP256K1}
-FP_LIMBS = {BLS12_381_G1: 6, SECP256K1: 4}
+ED25519 = 2   # edwards25519 / "Ristretto-class": no reference counterpart (parity unpinned, csrc/ed25519.hpp)
+CURVE_IDS = {"bls12_381": BLS12_381_G1, "secp256k1": SECP256K1, "ed25519": ED25519}
+FP_LIMBS = {BLS12_381_G1: 6, SECP256K1: 4, ED25519: 4}
 
 OK = 0
 VERIFICATION_ERROR = 1

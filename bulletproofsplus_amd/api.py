@@ -24,7 +24,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import BLS12_381_G1, SECP256K1, CURVE_IDS, BppError, check  # noqa: F401
+from ._lib import BLS12_381_G1, SECP256K1, ED25519, CURVE_IDS, BppError, check  # noqa: F401
 
 
 class ProofError(Exception):

@@ -11,7 +11,8 @@ extern "C" const char* bpp_last_error(void) { return g_err.c_str(); }
 
 extern "C" int bpp_init(int curve_id, int device, bpp_ctx** out_ctx) {
     if (!out_ctx) return fail(BPP_E_ARG, "null out_ctx");
-    if (curve_id != BPP_BLS12_381_G1 && curve_id != BPP_SECP256K1) return fail(BPP_E_ARG, "unknown curve id");
+    if (curve_id != BPP_BLS12_381_G1 && curve_id != BPP_SECP256K1 && curve_id != BPP_ED25519)
+        return fail(BPP_E_ARG, "unknown curve id");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(BPP_E_HIP, "no such HIP device");
@@ -25,6 +26,7 @@ extern "C" int bpp_point_words(int curve_id) {
     switch (curve_id) {
         case BPP_BLS12_381_G1: return 2 * 6 + 1;
         case BPP_SECP256K1: return 2 * 4 + 1;
+        case BPP_ED25519: return 2 * 4 + 1;
         default: return BPP_E_ARG;
     }
 }
@@ -150,7 +152,12 @@ extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, co
 // ---- combined batch check ------------------------------------------------------------------------------
 extern "C" size_t bpp_verifier_partial_bytes(const bpp_verifier* v) {
     if (!v) return 0;
-    return v->ctx.curve == BPP_BLS12_381_G1 ? 3 * 12 * 4 : 3 * 8 * 4;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = (size_t)jac_words<decltype(cv)>() * 4;
+        return 0;
+    });
+    return r;
 }
 extern "C" size_t bpp_verifier_combined_workspace_bytes(const bpp_verifier* v, size_t count) {
     if (!v) return 0;

@@ -107,12 +107,13 @@ template <class C>
 __global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __restrict__ partials, uint32_t n,
                                                           uint32_t* __restrict__ ok, uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t lane_zero;  // keeps the wave-uniform chain on the vector unit (see k_pip_final)
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     partials += lane_zero;
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t t = 0; t < n; t++) acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * 3 * N));
+    for (uint32_t t = 0; t < n; t++) acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * JW));
     ok[0] = acc.is_inf() ? 0u : 1u;
     if (out) jac_stg<C>(out, acc);
 }

@@ -33,6 +33,13 @@ struct Secp256k1 {
     static constexpr int ID = 1;
 };
 
+// 32-bit words of the packed projective ("jacobian") image of a point: 3 coordinates for the
+// short-Weierstrass curves
+template <class C>
+constexpr int jac_words() {
+    return 3 * C::Fp::N;
+}
+
 template <class C>
 struct Aff {
     Fe<typename C::Fp> x, y;

@@ -54,6 +54,7 @@ inline int dispatch(int curve, F&& f) {
     switch (curve) {
         case BPP_BLS12_381_G1: return f(Bls12381{});
         case BPP_SECP256K1: return f(Secp256k1{});
+        case BPP_ED25519: return f(Ed25519{});
         default: return fail(BPP_E_ARG, "unknown curve id");
     }
 }

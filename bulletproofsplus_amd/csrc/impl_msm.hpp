@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(64) k_dbg_point(int op, const uint32_t* a, con
 template <class C>
 struct MsmImpl {
     static constexpr int N = C::Fp::N;
+    static constexpr int JW = jac_words<C>();
     static constexpr int WW = 2 * N + 2;  // 32-bit words per wire point
     static constexpr int PW = WW / 2;     // 64-bit words per wire point
 
@@ -82,10 +83,10 @@ struct MsmImpl {
         unsigned gx = std::max(1u, std::min(cdiv(maxlen, block), 1024u));
         DevBuf doff, dpart, dout;
         HIPCHK(doff.alloc(offsets.size() * 8));
-        HIPCHK(dpart.alloc(count * gx * 3 * N * 4));
+        HIPCHK(dpart.alloc(count * gx * JW * 4));
         HIPCHK(dout.alloc(count * WW * 4));
         HIPCHK(hipMemcpyAsync(doff.p, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_msm_naive_partial<C>, dim3(gx, (unsigned)count), dim3(block), block * 3 * N * 4, st,
+        hipLaunchKernelGGL(k_msm_naive_partial<C>, dim3(gx, (unsigned)count), dim3(block), block * JW * 4, st,
                            d_scalars, d_points, static_cast<const uint64_t*>(doff.p), dpart.u32());
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_jac_reduce<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, dpart.u32(), gx, dout.u32(), count);
@@ -104,7 +105,7 @@ struct MsmImpl {
         const PipWorkspace pw = pip_workspace<C>(ps);
         DevBuf ws, res, dout;
         HIPCHK(ws.alloc(pw.total));
-        HIPCHK(res.alloc(3 * N * 4));
+        HIPCHK(res.alloc(JW * 4));
         HIPCHK(dout.alloc(WW * 4));
         HIPCHK(pip_launch<C>(ps, d_scalars, d_points, static_cast<uint8_t*>(ws.p), nullptr, 0, res.u32(), st));
         hipLaunchKernelGGL(k_jac_reduce<C>, dim3(1), dim3(64), 0, st, res.u32(), 1u, dout.u32(), (size_t)1);
@@ -303,5 +304,6 @@ struct MsmImpl {
 
 extern template struct MsmImpl<Bls12381>;
 extern template struct MsmImpl<Secp256k1>;
+extern template struct MsmImpl<Ed25519>;
 
 }  // namespace bpp

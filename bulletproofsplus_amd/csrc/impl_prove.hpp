@@ -276,5 +276,6 @@ static int range_prove(const uint64_t* gh, const uint64_t* G, const uint64_t* H,
 
 extern template struct ProveImpl<Bls12381>;
 extern template struct ProveImpl<Secp256k1>;
+extern template struct ProveImpl<Ed25519>;
 
 }  // namespace bpp

@@ -44,6 +44,7 @@ struct WsLayout {
 template <class C>
 struct VerifyImpl {
     static constexpr int N = C::Fp::N;
+    static constexpr int JW = jac_words<C>();
     static constexpr int WW = 2 * N + 2;
     static constexpr int PW = WW / 2;
 
@@ -58,11 +59,11 @@ struct VerifyImpl {
         w.scalars = o;
         o += al(count * (size_t)s.N * 32);
         w.fpart = o;
-        o += al(count * blocks_per_proof(s, count) * 3 * N * 4);
+        o += al(count * blocks_per_proof(s, count) * JW * 4);
         w.vpart = o;
-        o += al(count * s.NV * 3 * N * 4);
+        o += al(count * s.NV * JW * 4);
         w.vtbl = o;
-        o += al(count * s.NV * 8 * 3 * N * 4);
+        o += al(count * s.NV * 8 * JW * 4);
         w.total = o;
         return w;
     }
@@ -149,13 +150,13 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         if (ev) HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st,
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
                            s, w_sc, v->table.u32(), w_fp, bpp_);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
         hipLaunchKernelGGL(k_var_msm<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_sc, w_pts, w_vt,
                            w_vp, npts);
         if (ev) HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * 3 * N * 4, st, w_fp, bpp_, w_vp, s.NV,
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, s.NV,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         if (ev) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());
@@ -186,7 +187,7 @@ struct VerifyImpl {
         w.comb_sc = o;
         o += al((size_t)s.N * 32);
         w.fpart = o;
-        o += al((size_t)w.fixed_blocks * 3 * N * 4);
+        o += al((size_t)w.fixed_blocks * JW * 4);
         w.var_sc = o;
         o += al(items * 32);
         w.pip = o;
@@ -222,7 +223,7 @@ struct VerifyImpl {
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * 3 * N * 4, st, s,
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st, s,
                            w_cs, v->table.u32(), w_fp, L.fixed_blocks);
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
         HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
@@ -264,7 +265,7 @@ struct VerifyImpl {
             HIPCHK(d_pwy.alloc(vec));
             HIPCHK(d_con.alloc(cnt * (size_t)pb_consts_elems(k) * 32));
             HIPCHK(d_vps.alloc(nv_total * (size_t)s.N * 32));
-            HIPCHK(d_part.alloc(nv_total * per * 3 * N * 4));
+            HIPCHK(d_part.alloc(nv_total * per * JW * 4));
             HIPCHK(d_pts.alloc(cnt * (size_t)(3 + 2 * k) * WW * 4));
             HIPCHK(d_V.alloc(cnt * (size_t)m * WW * 4));
             HIPCHK(d_sc.alloc(cnt * 3 * 32));
@@ -277,7 +278,7 @@ struct VerifyImpl {
             hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
                                d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
             hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
-                               FIXED_BLOCK * 3 * N * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per);
+                               FIXED_BLOCK * JW * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per);
             hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
                                d_pts.u32(), d_V.u32(), nv_total);
             HIPCHK(hipGetLastError());
@@ -301,5 +302,6 @@ struct VerifyImpl {
 
 extern template struct VerifyImpl<Bls12381>;
 extern template struct VerifyImpl<Secp256k1>;
+extern template struct VerifyImpl<Ed25519>;
 
 }  // namespace bpp

@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec.hpp"
+#include "ed25519.hpp"
 
 namespace bpp {
 
@@ -67,6 +68,7 @@ __device__ __forceinline__ void st_words(uint32_t* __restrict__ p, const uint32_
 template <class C>
 __device__ __forceinline__ Aff<C> aff_ldg(const uint32_t* __restrict__ p) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     uint32_t w[2 * N];
     ld_words<2 * N>(p, w);
     return aff_load<C>(w);
@@ -74,6 +76,7 @@ __device__ __forceinline__ Aff<C> aff_ldg(const uint32_t* __restrict__ p) {
 template <class C>
 __device__ __forceinline__ void aff_stg(uint32_t* __restrict__ p, const Aff<C>& a) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     uint32_t w[2 * N];
     aff_store(a, w);
     st_words<2 * N>(p, w);
@@ -81,16 +84,18 @@ __device__ __forceinline__ void aff_stg(uint32_t* __restrict__ p, const Aff<C>& 
 template <class C>
 __device__ __forceinline__ Jac<C> jac_ldg(const uint32_t* __restrict__ p) {
     constexpr int N = C::Fp::N;
-    uint32_t w[3 * N];
-    ld_words<3 * N>(p, w);
+    constexpr int JW = jac_words<C>();
+    uint32_t w[JW];
+    ld_words<JW>(p, w);
     return jac_load<C>(w);
 }
 template <class C>
 __device__ __forceinline__ void jac_stg(uint32_t* __restrict__ p, const Jac<C>& a) {
     constexpr int N = C::Fp::N;
-    uint32_t w[3 * N];
+    constexpr int JW = jac_words<C>();
+    uint32_t w[JW];
     jac_store(a, w);
-    st_words<3 * N>(p, w);
+    st_words<JW>(p, w);
 }
 
 // Sum of the jacobian accumulators of a thread block.  `lds` holds blockDim.x * 3N words.
@@ -98,11 +103,12 @@ __device__ __forceinline__ void jac_stg(uint32_t* __restrict__ p, const Jac<C>& 
 template <class C>
 __device__ __forceinline__ Jac<C> block_reduce_jac(Jac<C> acc, uint32_t* lds) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const int tid = threadIdx.x;
     for (int half = blockDim.x >> 1; half >= 1; half >>= 1) {
-        if (tid >= half && tid < 2 * half) jac_store(acc, lds + (size_t)tid * 3 * N);
+        if (tid >= half && tid < 2 * half) jac_store(acc, lds + (size_t)tid * JW);
         __syncthreads();
-        if (tid < half) acc = jac_add(acc, jac_load<C>(lds + (size_t)(tid + half) * 3 * N));
+        if (tid < half) acc = jac_add(acc, jac_load<C>(lds + (size_t)(tid + half) * JW));
         __syncthreads();
     }
     return acc;
@@ -116,6 +122,7 @@ template <class C>
 __global__ void __launch_bounds__(128) k_points_from_wire(const uint32_t* __restrict__ wire, uint32_t* __restrict__ affm,
                                    uint32_t* __restrict__ bad, size_t n, uint32_t per_group) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t w[2 * N + 2];
@@ -133,6 +140,7 @@ __global__ void __launch_bounds__(128) k_points_from_wire(const uint32_t* __rest
 template <class C>
 __global__ void __launch_bounds__(64) k_points_to_wire(const uint32_t* __restrict__ affm, uint32_t* __restrict__ wire, size_t n) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Aff<C> p = aff_ldg<C>(affm + i * 2 * N);
@@ -149,6 +157,7 @@ template <class C>
 __global__ void __launch_bounds__(64) k_scalar_mul(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
                              size_t point_stride, uint32_t* __restrict__ out, size_t n) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k[8];
@@ -165,6 +174,7 @@ template <class C>
 __global__ void __launch_bounds__(MSM_BLOCK) k_msm_naive_partial(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
                                     const uint64_t* __restrict__ offsets, uint32_t* __restrict__ partials) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
     const size_t c = blockIdx.y;
     const size_t beg = offsets[c], end = offsets[c + 1];
@@ -177,7 +187,7 @@ __global__ void __launch_bounds__(MSM_BLOCK) k_msm_naive_partial(const uint32_t*
         acc = jac_add(acc, aff_mul_words(p, k, 8));
     }
     acc = block_reduce_jac<C>(acc, lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (c * gridDim.x + blockIdx.x) * 3 * N, acc);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (c * gridDim.x + blockIdx.x) * JW, acc);
 }
 
 // one thread per MulVec: sums its `per` jacobian partials, writes the wire point (affine, canonical)
@@ -185,10 +195,11 @@ template <class C>
 __global__ void __launch_bounds__(64) k_jac_reduce(const uint32_t* __restrict__ partials, uint32_t per, uint32_t* __restrict__ wire_out,
                              size_t count) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (c * per + t) * 3 * N));
+    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (c * per + t) * JW));
     uint32_t w[2 * N + 2];
     aff_to_wire(jac_to_aff(acc), w);
 #pragma unroll
@@ -540,6 +551,7 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
 template <class C>
 __global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t* __restrict__ fixed_pts, uint32_t* __restrict__ table) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= s.NF) return;
     Aff<C> p = aff_ldg<C>(fixed_pts + (size_t)f * 2 * N);
@@ -557,6 +569,7 @@ __global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t*
 template <class C>
 __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t f_begin, uint32_t f_end) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t per_f = (size_t)s.W * s.half;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(f_end - f_begin) * per_f;
@@ -581,6 +594,7 @@ template <class C>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
     // flat grid: block = proof * per + part   (`per` blocks share one proof's generators)
     const size_t b = blockIdx.x / per;
@@ -633,12 +647,12 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
     fetch();
     while (have) {
         Aff<C> cur = aff_load<C>(raw);
-        if (nneg) cur.y = fe_neg(cur.y);
+        if (nneg) cur = aff_neg(cur);
         fetch();
         acc = xyzz_madd(acc, cur);
     }
     Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)blockIdx.x * 3 * N, sum);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)blockIdx.x * JW, sum);
 }
 
 // Proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments.  One lane per
@@ -651,6 +665,7 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShap
                                                        uint32_t* __restrict__ tbl, uint32_t* __restrict__ out,
                                                        size_t items) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= items) return;
     const size_t b = item / s.NV;
@@ -669,22 +684,22 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShap
         }
     }
     const Aff<C> p = aff_ldg<C>(proof_pts + item * 2 * N);
-    uint32_t* T = tbl + item * 8 * 3 * N;
+    uint32_t* T = tbl + item * 8 * JW;
     {
         Jac<C> t1 = jac_from_aff(p);
         Jac<C> t2 = aff_dbl(p);
         Jac<C> t3 = jac_madd(t2, p);
         Jac<C> t4 = jac_dbl(t2);
         jac_stg<C>(T, t1);
-        jac_stg<C>(T + 3 * N, t2);
-        jac_stg<C>(T + 2 * 3 * N, t3);
-        jac_stg<C>(T + 3 * 3 * N, t4);
+        jac_stg<C>(T + JW, t2);
+        jac_stg<C>(T + 2 * JW, t3);
+        jac_stg<C>(T + 3 * JW, t4);
         Jac<C> t5 = jac_madd(t4, p);
         Jac<C> t6 = jac_dbl(t3);
-        jac_stg<C>(T + 4 * 3 * N, t5);
-        jac_stg<C>(T + 5 * 3 * N, t6);
-        jac_stg<C>(T + 6 * 3 * N, jac_madd(t6, p));
-        jac_stg<C>(T + 7 * 3 * N, jac_dbl(t4));
+        jac_stg<C>(T + 4 * JW, t5);
+        jac_stg<C>(T + 5 * JW, t6);
+        jac_stg<C>(T + 6 * JW, jac_madd(t6, p));
+        jac_stg<C>(T + 7 * JW, jac_dbl(t4));
     }
     Jac<C> acc = jac_inf<C>();
     for (int j = 64; j >= 0; j--) {
@@ -701,12 +716,12 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShap
         }
         if (dg != 0) {
             const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
-            Jac<C> q = jac_ldg<C>(T + (size_t)(mag - 1) * 3 * N);
-            if (dg < 0) q.Y = fe_neg(q.Y);
+            Jac<C> q = jac_ldg<C>(T + (size_t)(mag - 1) * JW);
+            if (dg < 0) q = jac_neg(q);
             acc = jac_add(acc, q);
         }
     }
-    jac_stg<C>(out + item * 3 * N, acc);
+    jac_stg<C>(out + item * JW, acc);
 }
 
 // expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError
@@ -718,11 +733,12 @@ __global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fi
                                                  const uint32_t* __restrict__ bad, uint32_t* __restrict__ ok,
                                                  uint32_t* __restrict__ wire_result) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
     const size_t b = blockIdx.x;
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = threadIdx.x; t < per + nv; t += blockDim.x) {
-        const uint32_t* src = t < per ? fixed_partials + (b * per + t) * 3 * N : var_partials + (b * nv + (t - per)) * 3 * N;
+        const uint32_t* src = t < per ? fixed_partials + (b * per + t) * JW : var_partials + (b * nv + (t - per)) * JW;
         acc = jac_add(acc, jac_ldg<C>(src));
     }
     acc = block_reduce_jac<C>(acc, lds);

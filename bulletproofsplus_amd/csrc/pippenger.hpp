@@ -152,6 +152,7 @@ __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32
                                                         uint32_t* __restrict__ heavy_list,
                                                         uint32_t* __restrict__ heavy_count) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)s.W * s.half) return;
     const uint32_t j = (uint32_t)(gid / s.half);
@@ -165,10 +166,10 @@ __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32
     for (uint32_t t = 0; t < cnt; t++) {
         const uint32_t e = row[beg + t];
         Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
-        if (e & 1u) q.y = fe_neg(q.y);
+        if (e & 1u) q = aff_neg(q);
         acc = xyzz_madd(acc, q);
     }
-    jac_stg<C>(buckets + gid * 3 * N, xyzz_to_jac(acc));
+    jac_stg<C>(buckets + gid * JW, xyzz_to_jac(acc));
 }
 
 // grid (any, PIP_SPLIT): block (h, part) sums part `part` of heavy bucket heavy_list[h] with 128 lanes and an
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(128, 2) k_pip_heavy(PipShape s, const uint32_t
                                                       const uint32_t* __restrict__ heavy_count,
                                                       uint32_t* __restrict__ heavy_parts) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
@@ -195,11 +197,11 @@ __global__ void __launch_bounds__(128, 2) k_pip_heavy(PipShape s, const uint32_t
         for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
             const uint32_t e = row[t];
             Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
-            if (e & 1u) q.y = fe_neg(q.y);
+            if (e & 1u) q = aff_neg(q);
             acc = xyzz_madd(acc, q);
         }
         Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
-        if (threadIdx.x == 0) jac_stg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + blockIdx.y) * 3 * N, sum);
+        if (threadIdx.x == 0) jac_stg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + blockIdx.y) * JW, sum);
         __syncthreads();
     }
 }
@@ -211,12 +213,13 @@ __global__ void __launch_bounds__(64) k_pip_heavy_fold(const uint32_t* __restric
                                                        const uint32_t* __restrict__ heavy_parts,
                                                        uint32_t* __restrict__ buckets) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const uint32_t nheavy = *heavy_count;
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheavy; h += gridDim.x * blockDim.x) {
         Jac<C> acc = jac_inf<C>();
         for (uint32_t t = 0; t < PIP_SPLIT; t++)
-            acc = jac_add(acc, jac_ldg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + t) * 3 * N));
-        jac_stg<C>(buckets + (size_t)heavy_list[h] * 3 * N, acc);
+            acc = jac_add(acc, jac_ldg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + t) * JW));
+        jac_stg<C>(buckets + (size_t)heavy_list[h] * JW, acc);
     }
 }
 
@@ -227,6 +230,7 @@ template <class C>
 __global__ void __launch_bounds__(PIP_WIN_BLOCK) k_pip_windows(PipShape s, const uint32_t* __restrict__ buckets,
                                                         uint32_t* __restrict__ window_sums) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t j = blockIdx.x, t = threadIdx.x;
     const uint32_t S = max(1u, s.half / blockDim.x);
@@ -234,10 +238,10 @@ __global__ void __launch_bounds__(PIP_WIN_BLOCK) k_pip_windows(PipShape s, const
     Jac<C> total = jac_inf<C>();
     if (lo < s.half) {
         const uint32_t hi = min(lo + S, s.half);
-        const uint32_t* bj = buckets + (size_t)j * s.half * 3 * N;
+        const uint32_t* bj = buckets + (size_t)j * s.half * JW;
         Jac<C> run = jac_inf<C>(), acc = jac_inf<C>();
         for (uint32_t b = hi; b-- > lo;) {
-            run = jac_add(run, jac_ldg<C>(bj + (size_t)b * 3 * N));
+            run = jac_add(run, jac_ldg<C>(bj + (size_t)b * JW));
             acc = jac_add(acc, run);
         }
         // + lo * run
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(PIP_WIN_BLOCK) k_pip_windows(PipShape s, const
         total = jac_add(acc, off);
     }
     total = block_reduce_jac<C>(total, lds);
-    if (t == 0) jac_stg<C>(window_sums + (size_t)j * 3 * N, total);
+    if (t == 0) jac_stg<C>(window_sums + (size_t)j * JW, total);
 }
 
 // Horner over the windows; the result is ADDED to `extra` partials (may be none) and written as one
@@ -259,6 +263,7 @@ __global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __
                                                   const uint32_t* __restrict__ extra, uint32_t n_extra,
                                                   uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     // Everything below depends only on kernel arguments, i.e. is wave-uniform, and hipcc would compile it
     // to the SCALAR unit (s_mul_i32 / s_mul_hi_u32 / s_addc_u32: ~4 instructions per limb product).  An
@@ -270,9 +275,9 @@ __global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __
     for (uint32_t j = s.W; j-- > 0;) {
         if (!acc.is_inf())
             for (uint32_t t = 0; t < s.c; t++) acc = jac_dbl(acc);
-        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)j * 3 * N));
+        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)j * JW));
     }
-    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + lane_zero + (size_t)t * 3 * N));
+    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + lane_zero + (size_t)t * JW));
     jac_stg<C>(out, acc);
 }
 
@@ -283,6 +288,7 @@ struct PipWorkspace {
 template <class C>
 inline PipWorkspace pip_workspace(const PipShape& s) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     PipWorkspace w;
     size_t o = 0;
@@ -297,9 +303,9 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     w.offsets = o;
     o += al((size_t)s.W * s.half * 4);
     w.buckets = o;
-    o += al((size_t)s.W * s.half * 3 * N * 4);
+    o += al((size_t)s.W * s.half * JW * 4);
     w.wsums = o;
-    o += al((size_t)s.W * 3 * N * 4);
+    o += al((size_t)s.W * JW * 4);
     // a heavy bucket holds > PIP_HEAVY of the W * n sorted entries
     w.max_heavy = std::min<size_t>((size_t)s.W * s.half, (size_t)s.W * s.n / PIP_HEAVY + 1);
     w.hlist = o;
@@ -307,7 +313,7 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     w.hcount = o;
     o += al(4);
     w.hparts = o;
-    o += al(w.max_heavy * PIP_SPLIT * 3 * N * 4);
+    o += al(w.max_heavy * PIP_SPLIT * JW * 4);
     w.total = o;
     return w;
 }
@@ -317,6 +323,7 @@ template <class C>
 inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const uint32_t* d_points, uint8_t* d_ws,
                              const uint32_t* d_extra, uint32_t n_extra, uint32_t* d_out, hipStream_t st) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     const PipWorkspace w = pip_workspace<C>(s);
     uint32_t* keys = reinterpret_cast<uint32_t*>(d_ws + w.keys);
     uint32_t* slots = reinterpret_cast<uint32_t*>(d_ws + w.slots);
@@ -339,14 +346,14 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     hipLaunchKernelGGL(k_pip_buckets<C>, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, st, s, d_points, sorted,
                        offsets, counts, buckets, hlist, hcount);
     const unsigned hgrid = (unsigned)std::min<size_t>(w.max_heavy, 2048);
-    hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * 3 * N * 4, st, s, d_points, sorted,
+    hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * JW * 4, st, s, d_points, sorted,
                        offsets, counts, hlist, hcount, hparts);
     hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3((hgrid + 63) / 64), dim3(64), 0, st, hlist, hcount, hparts, buckets);
     // 512 lanes x 144 B of LDS exceed the 64 KB default for dynamic LDS: opt in (160 KB per CU on gfx950)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pip_windows<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(PIP_WIN_BLOCK * 3 * N * 4));
+                            (int)(PIP_WIN_BLOCK * JW * 4));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(PIP_WIN_BLOCK), PIP_WIN_BLOCK * 3 * N * 4, st, s, buckets, wsums);
+    hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(PIP_WIN_BLOCK), PIP_WIN_BLOCK * JW * 4, st, s, buckets, wsums);
     hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(64), 0, st, s, wsums, d_extra, n_extra, d_out);
     return hipGetLastError();
 }

@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(64) k_pb_collect(VerifyShape s, const uint32_t
                                                    uint32_t* __restrict__ out_points, uint32_t* __restrict__ out_V,
                                                    size_t nvp_total) {
     constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
     constexpr int WW = 2 * N + 2;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nvp_total) return;
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(64) k_pb_collect(VerifyShape s, const uint32_t
     const size_t p = g / nvp;
     const uint32_t v = (uint32_t)(g % nvp);
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (g * per + t) * 3 * N));
+    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (g * per + t) * JW));
     uint32_t w[WW];
     aff_to_wire(jac_to_aff(acc), w);
     uint32_t* dst;

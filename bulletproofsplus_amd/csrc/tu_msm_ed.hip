@@ -1,0 +1,5 @@
+// explicit instantiation: MsmImpl<Ed25519> (its kernels are compiled in this translation unit only)
+#include "impl_msm.hpp"
+namespace bpp {
+template struct MsmImpl<Ed25519>;
+}

@@ -37,6 +37,9 @@ extern "C" {
  * secp256k1 is its second, in-tree backend (src/secp256k1/building_block/). */
 #define BPP_BLS12_381_G1 0
 #define BPP_SECP256K1 1
+/* edwards25519 (the curve under Ristretto255), prime-order subgroup, points as affine Edwards (x, y), L = 4.
+ * The reference has NO such backend (only a stale README example): parity unpinned, see csrc/ed25519.hpp. */
+#define BPP_ED25519 2
 
 #define BPP_OK 0
 #define BPP_VERIFICATION_ERROR 1

@@ -18,7 +18,8 @@ _SO = os.path.join(_HERE, "libbpp_oracle.so")
 
 BLS12_381 = 0
 SECP256K1 = 1
-CURVE_IDS = {"bls12_381": BLS12_381, "secp256k1": SECP256K1}
+ED25519 = 2   # wire-format helpers only: the C oracle has no Edwards backend (pyref.EdwardsGroup is the checker)
+CURVE_IDS = {"bls12_381": BLS12_381, "secp256k1": SECP256K1, "ed25519": ED25519}
 
 
 def build(force: bool = False) -> str:
@@ -46,11 +47,11 @@ def _p(a: np.ndarray):
 
 
 def fp_limbs(curve: int) -> int:
-    return lib().orc_fp_limbs(curve)
+    return 4 if curve == ED25519 else lib().orc_fp_limbs(curve)
 
 
 def point_words(curve: int) -> int:
-    return lib().orc_point_words(curve)
+    return 9 if curve == ED25519 else lib().orc_point_words(curve)
 
 
 # ---- int <-> wire helpers ------------------------------------------------------------------

@@ -65,7 +65,20 @@ SECP256K1 = dict(
     fp_bytes=32,
 )
 
-CURVES = {"bls12_381": BLS12_381, "secp256k1": SECP256K1}
+_ED_P = (1 << 255) - 19
+ED25519 = dict(
+    name="ed25519",
+    # edwards25519 (RFC 8032).  NOT a backend of the reference: used only to check the
+    # engine's third instantiation; parity unpinned.
+    p=_ED_P,
+    r=(1 << 252) + 27742317777372353535851937790883648493,
+    d=(-121665 * pow(121666, -1, _ED_P)) % _ED_P,
+    gx=15112221349535400772501151409588531511454012693041857206046113283949847762202,
+    gy=4 * pow(5, -1, _ED_P) % _ED_P,
+    fp_bytes=32,
+)
+
+CURVES = {"bls12_381": BLS12_381, "secp256k1": SECP256K1, "ed25519": ED25519}
 
 
 # --------------------------------------------------------------------------------------
@@ -157,6 +170,59 @@ class WeierstrassGroup:
     def mul(self, P, k):
         # LSB-first double-and-add, reference macros.rs:9-27.  k is NOT reduced: the
         # reference's secp256k1 tests pass base-field elements as scalars (affine_point.rs:258).
+        res = None
+        q = P
+        while k:
+            if k & 1:
+                res = self.add(res, q)
+            q = self.add(q, q)
+            k >>= 1
+        return res
+
+    def eq(self, P, Q):
+        return P == Q
+
+
+class EdwardsGroup:
+    """-x^2 + y^2 = 1 + d x^2 y^2 over F_p (a = -1), affine; the identity (0, 1) is represented as None so
+    that the wire format (inf flag) matches the Weierstrass backends."""
+
+    def __init__(self, curve: dict):
+        self.c = curve
+        self.p = curve["p"]
+        self.r = curve["r"]
+        self.d = curve["d"]
+
+    def base(self):
+        return (self.c["gx"], self.c["gy"])
+
+    def zero(self):
+        return None
+
+    def is_zero(self, P):
+        return P is None
+
+    def on_curve(self, P):
+        if P is None:
+            return True
+        x, y = P
+        return (-x * x + y * y - 1 - self.d * x * x * y * y) % self.p == 0
+
+    def neg(self, P):
+        if P is None:
+            return None
+        return ((-P[0]) % self.p, P[1])
+
+    def add(self, P, Q):
+        p, d = self.p, self.d
+        x1, y1 = (0, 1) if P is None else P
+        x2, y2 = (0, 1) if Q is None else Q
+        t = d * x1 * x2 * y1 * y2 % p
+        x3 = (x1 * y2 + y1 * x2) * pow(1 + t, -1, p) % p
+        y3 = (y1 * y2 + x1 * x2) * pow(1 - t, -1, p) % p
+        return None if (x3 == 0 and y3 == 1) else (x3, y3)
+
+    def mul(self, P, k):
         res = None
         q = P
         while k:
@@ -729,7 +795,9 @@ class RangeProof:
 
 def make_group(curve_name: str, shadow: bool):
     c = CURVES[curve_name]
-    return ShadowGroup(c["r"]) if shadow else WeierstrassGroup(c)
+    if shadow:
+        return ShadowGroup(c["r"])
+    return EdwardsGroup(c) if curve_name == "ed25519" else WeierstrassGroup(c)
 
 
 def prove_case(curve_name: str, n: int, values, gammas, shadow=True, trace=None):
