@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="proofs per GPU per step")
     ap.add_argument("--distinct", type=int, default=0, help="distinct proofs per GPU; 0 = all of --batch distinct, else tiled")
-    ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "secp256k1"])
+    ap.add_argument("--curve", default="bls12_381", choices=["bls12_381", "secp256k1", "ed25519"])
     ap.add_argument("--n", type=int, default=64)
     ap.add_argument("--m", type=int, default=16)
     ap.add_argument("--window", type=int, default=16)
@@ -254,7 +254,7 @@ def main():
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},
         }
         thr = args.cpu_threads
-        if thr >= 0 and world == 1:
+        if thr >= 0 and world == 1 and args.curve != "ed25519":   # the C oracle has no Edwards backend
             thr = thr or min(8, os.cpu_count() or 1)
             v, cdt = cpu_baseline(n, m, args.curve, thr, args.cpu_per_thread)
             out["cpu_baseline"] = {"value": v, "unit": "verifies/s", "cores": thr, "kind": "port",

@@ -38,7 +38,7 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
 }
 
 struct WsLayout {
-    size_t pts, bad, scalars, fpart, vpart, vtbl, total;
+    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, total;
 };
 
 template <class C>
@@ -61,9 +61,13 @@ struct VerifyImpl {
         w.fpart = o;
         o += al(count * blocks_per_proof(s, count) * JW * 4);
         w.vpart = o;
-        o += al(count * s.NV * JW * 4);
+        o += al(count * JW * 4);                                   // one jacobian per proof
+        w.vdig = o;
+        o += al(count * s.NV * VAR_DIGIT_STRIDE);                  // 65 digit bytes per proof point
+        w.vwsum = o;
+        o += al(count * VAR_WINDOWS * JW * 4);                     // window sums
         w.vtbl = o;
-        o += al(count * s.NV * 8 * JW * 4);
+        o += al(count * VAR_WINDOWS * 8 * JW * 4);                 // 8 lane-private buckets per (proof, window)
         w.total = o;
         return w;
     }
@@ -153,10 +157,15 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
                            s, w_sc, v->table.u32(), w_fp, bpp_);
         if (ev) HIPCHK(hipEventRecord(ev[3], st));
-        hipLaunchKernelGGL(k_var_msm<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_sc, w_pts, w_vt,
-                           w_vp, npts);
+        uint8_t* w_vd = ws + L.vdig;
+        uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
+        const size_t vlanes = count * VAR_WINDOWS;
+        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts);
+        hipLaunchKernelGGL(k_var_buckets<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_pts, w_vt,
+                           w_vw, vlanes);
+        hipLaunchKernelGGL(k_var_horner<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_vw, w_vp, count);
         if (ev) HIPCHK(hipEventRecord(ev[4], st));
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, s.NV,
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         if (ev) HIPCHK(hipEventRecord(ev[5], st));
         HIPCHK(hipGetLastError());

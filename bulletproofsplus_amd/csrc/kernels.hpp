@@ -17,7 +17,7 @@
 //                                                               wip.rs:254-295
 //   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables
 //                                                               range/mod.rs:480-503 / wip.rs:297-320
-//   k_var_msm            the 3+2k+m proof-dependent terms of the same MulVec
+//   k_var_digits/buckets/horner  the 3+2k+m proof-dependent terms of the same MulVec (bucket method per proof)
 //   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327
 //   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new)
 #pragma once
@@ -655,17 +655,18 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
     if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)blockIdx.x * JW, sum);
 }
 
-// Proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments.  One lane per
-// (proof, point) so that every lane of every wave is busy; fixed 4-bit signed windows: 65 digits in
-// [-8, 8) from (scalar + 0x88..8), a lane-private table of 1..8 multiples (jacobian, in HBM scratch, L2
-// resident), then 4 doublings + 1 addition per window.  out / tbl are indexed by item = proof * NV + v.
+// ---- proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments ---------------
+// A bucket method PER PROOF so that the ~260 doublings are paid once per proof, not once per point:
+//   k_var_digits   one lane per (proof, point): 65 signed 4-bit digits of (scalar + 0x88..8), one byte each
+//   k_var_buckets  one lane per (proof, window): the proof's NV points go into 8 lane-private buckets
+//                  (jacobian, HBM scratch that stays in L2 / Infinity Cache), then sum_k k * B_k
+//   k_var_horner   one lane per proof: Horner over the 65 window sums (4 doublings per step)
+constexpr uint32_t VAR_WINDOWS = 65;   // 4-bit windows of a 260-bit value
+constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple)
+
 template <class C>
-__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
-                                                       const uint32_t* __restrict__ proof_pts,
-                                                       uint32_t* __restrict__ tbl, uint32_t* __restrict__ out,
-                                                       size_t items) {
-    constexpr int N = C::Fp::N;
-    constexpr int JW = jac_words<C>();
+__global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_t* __restrict__ scalars,
+                                                    uint8_t* __restrict__ digits, size_t items) {
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= items) return;
     const size_t b = item / s.NV;
@@ -673,55 +674,81 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_msm(VerifyShap
     uint32_t w[9];
     ld_words<8>(scalars + (b * s.N + var_term_index(s, v)) * 8, w);
     w[8] = 0;
-    {   // + 0x8888...8 (65 nibbles)
-        uint32_t carry = 0;
+    uint32_t carry = 0;
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const uint32_t kw = t < 8 ? 0x88888888u : 0x8u;
-            uint64_t x = (uint64_t)w[t] + kw + carry;
-            w[t] = (uint32_t)x;
-            carry = (uint32_t)(x >> 32);
-        }
+    for (int t = 0; t < 9; t++) {
+        const uint32_t kw = t < 8 ? 0x88888888u : 0x8u;
+        uint64_t x = (uint64_t)w[t] + kw + carry;
+        w[t] = (uint32_t)x;
+        carry = (uint32_t)(x >> 32);
     }
-    const Aff<C> p = aff_ldg<C>(proof_pts + item * 2 * N);
-    uint32_t* T = tbl + item * 8 * JW;
-    {
-        Jac<C> t1 = jac_from_aff(p);
-        Jac<C> t2 = aff_dbl(p);
-        Jac<C> t3 = jac_madd(t2, p);
-        Jac<C> t4 = jac_dbl(t2);
-        jac_stg<C>(T, t1);
-        jac_stg<C>(T + JW, t2);
-        jac_stg<C>(T + 2 * JW, t3);
-        jac_stg<C>(T + 3 * JW, t4);
-        Jac<C> t5 = jac_madd(t4, p);
-        Jac<C> t6 = jac_dbl(t3);
-        jac_stg<C>(T + 4 * JW, t5);
-        jac_stg<C>(T + 5 * JW, t6);
-        jac_stg<C>(T + 6 * JW, jac_madd(t6, p));
-        jac_stg<C>(T + 7 * JW, jac_dbl(t4));
-    }
-    Jac<C> acc = jac_inf<C>();
-    for (int j = 64; j >= 0; j--) {
-        // digit j = the nibble now at bits 256..259; then shift the 288-bit value left by one nibble
-        const int32_t dg = (int32_t)(w[8] & 15u) - 8;
+    // digit j = nibble j minus 8, stored biased (nibble itself): 0..15, 8 means digit 0
+    uint32_t out[VAR_DIGIT_STRIDE / 4];
 #pragma unroll
-        for (int t = 8; t > 0; t--) w[t] = (w[t] << 4) | (w[t - 1] >> 28);
-        w[0] <<= 4;
+    for (int t = 0; t < (int)(VAR_DIGIT_STRIDE / 4); t++) out[t] = 0;
+#pragma unroll
+    for (int j = 0; j < (int)VAR_WINDOWS; j++) {
+        const uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
+        out[j >> 2] |= nib << ((j & 3) * 8);
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(digits + item * VAR_DIGIT_STRIDE);
+    st_words<VAR_DIGIT_STRIDE / 4>(dst, out);
+}
+
+// lane = (proof b, window j).  bucket scratch: [lane][8] jacobians.  wsum: [proof][VAR_WINDOWS] jacobians.
+template <class C>
+__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_buckets(VerifyShape s, const uint8_t* __restrict__ digits,
+                                                                         const uint32_t* __restrict__ proof_pts,
+                                                                         uint32_t* __restrict__ bucket_scratch,
+                                                                         uint32_t* __restrict__ wsum, size_t lanes) {
+    constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes) return;
+    const size_t b = lane / VAR_WINDOWS;
+    const uint32_t j = (uint32_t)(lane % VAR_WINDOWS);
+    uint32_t* B = bucket_scratch + lane * 8 * JW;
+    uint32_t occupied = 0;   // bit k: bucket k (digit magnitude k+1) holds a point
+    for (uint32_t v = 0; v < s.NV; v++) {
+        const int32_t dg = (int32_t)digits[(b * s.NV + v) * VAR_DIGIT_STRIDE + j] - 8;
+        if (dg == 0) continue;
+        const uint32_t kq = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
+        Aff<C> p = aff_ldg<C>(proof_pts + (b * s.NV + v) * 2 * N);
+        if (dg < 0) p = aff_neg(p);
+        Jac<C> acc;
+        if ((occupied >> kq) & 1u) acc = jac_madd(jac_ldg<C>(B + (size_t)kq * JW), p);
+        else acc = jac_from_aff(p);
+        occupied |= 1u << kq;
+        jac_stg<C>(B + (size_t)kq * JW, acc);
+    }
+    // sum_k (k+1) * B_k by descending running sums
+    Jac<C> run = jac_inf<C>(), tot = jac_inf<C>();
+    for (int kq = 7; kq >= 0; kq--) {
+        if ((occupied >> kq) & 1u) run = jac_add(run, jac_ldg<C>(B + (size_t)kq * JW));
+        tot = jac_add(tot, run);
+    }
+    jac_stg<C>(wsum + lane * JW, tot);
+}
+
+// one lane per proof: out[b] = sum_j 16^j * wsum[b][j]
+template <class C>
+__global__ void __launch_bounds__(64) k_var_horner(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out,
+                                                   size_t count) {
+    constexpr int JW = jac_words<C>();
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    const uint32_t* W = wsum + b * VAR_WINDOWS * JW;
+    Jac<C> acc = jac_ldg<C>(W + (size_t)(VAR_WINDOWS - 1) * JW);
+    for (int j = (int)VAR_WINDOWS - 2; j >= 0; j--) {
         if (!acc.is_inf()) {
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
         }
-        if (dg != 0) {
-            const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
-            Jac<C> q = jac_ldg<C>(T + (size_t)(mag - 1) * JW);
-            if (dg < 0) q = jac_neg(q);
-            acc = jac_add(acc, q);
-        }
+        acc = jac_add(acc, jac_ldg<C>(W + (size_t)j * JW));
     }
-    jac_stg<C>(out + item * JW, acc);
+    jac_stg<C>(out + b * JW, acc);
 }
 
 // expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError
