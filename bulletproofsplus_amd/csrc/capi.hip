@@ -193,7 +193,7 @@ extern "C" int bpp_verifier_set_profiling(bpp_verifier* v, int on) {
     if (!v) return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(v->ctx.device));
     if (on && v->events.empty()) {
-        v->events.resize((size_t)BPP_PROFILE_SLOTS * (BPP_NUM_STAGES + 1));
+        v->events.resize((size_t)BPP_PROFILE_SLOTS * BPP_NUM_STAGES * 2);
         for (hipEvent_t& e : v->events) HIPCHK(hipEventCreate(&e));
     }
     v->profiling = on != 0;
@@ -208,11 +208,11 @@ extern "C" int bpp_verifier_profile(bpp_verifier* v, float* out_stage_ms, size_t
     const size_t np = std::min<size_t>(v->passes_recorded, BPP_PROFILE_SLOTS);
     for (int t = 0; t < BPP_NUM_STAGES; t++) out_stage_ms[t] = 0.f;
     for (size_t p = 0; p < np; p++) {
-        hipEvent_t* ev = v->events.data() + p * (BPP_NUM_STAGES + 1);
-        HIPCHK(hipEventSynchronize(ev[BPP_NUM_STAGES]));
+        hipEvent_t* ev = v->events.data() + p * (BPP_NUM_STAGES * 2);
         for (int t = 0; t < BPP_NUM_STAGES; t++) {
+            HIPCHK(hipEventSynchronize(ev[2 * t + 1]));
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[t], ev[t + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, ev[2 * t], ev[2 * t + 1]));
             out_stage_ms[t] += ms;
         }
     }

@@ -7,9 +7,12 @@
 //
 // Representation (chosen for CDNA4, not translated from anything):
 //   * in REGISTERS an element is NL unsaturated 30-bit limbs (13 for the 381-bit field, 9 for the
-//     255/256-bit fields), fully reduced (< p) and normalised (every limb < 2^30), in Montgomery form
-//     with R = 2^(30*NL).
-//   * in MEMORY (HBM tables, proofs, wire) it is N packed 32-bit words (12 / 8) of the same value.
+//     255/256-bit fields), normalised (every limb < 2^30), in Montgomery form with R = 2^(30*NL), and
+//     LAZILY reduced: the value lies in [0, 2p), not [0, p).  With 4p < R a Montgomery product of two such
+//     values is < p (4p/R + 1) < 1.01 p, so fe_mul / fe_sqr need no final conditional subtraction; add and
+//     sub keep the invariant with one conditional +-2p.  Zero tests accept 0 and p; equality, canonical
+//     output and the packed memory image reduce fully.
+//   * in MEMORY (HBM tables, proofs, wire) it is N packed 32-bit words (12 / 8) of the fully reduced value.
 // Why 30-bit limbs: the only wide multiplier on gfx950 is v_mad_u64_u32 (32x32+64 -> 64).  It has a
 // carry-OUT but no carry-IN, and on gfx90a+/gfx950 a VALU carry written to VCC/SGPR needs two wait
 // states before a VALU instruction may read it, so a saturated 32-bit-limb schedule costs >= 3 issue
@@ -54,30 +57,29 @@ struct Fe {
         for (int i = 0; i < NL; i++) r.l[i] = P::R2[i];
         return r;
     }
+    // value == 0 mod p, for a value in [0, 2p): the limbs spell 0 or p
     BPP_HD bool is_zero() const {
-        uint32_t o = 0;
+        uint32_t o = 0, q = 0;
 #pragma unroll
-        for (int i = 0; i < NL; i++) o |= l[i];
-        return o == 0;
+        for (int i = 0; i < NL; i++) {
+            o |= l[i];
+            q |= l[i] ^ P::MOD[i];
+        }
+        return o == 0 || q == 0;
     }
-    BPP_HD bool operator==(const Fe& b) const {
-        uint32_t o = 0;
-#pragma unroll
-        for (int i = 0; i < NL; i++) o |= l[i] ^ b.l[i];
-        return o == 0;
-    }
+    BPP_HD bool operator==(const Fe& b) const;   // (a - b) == 0 mod p, defined after fe_sub
     BPP_HD bool operator!=(const Fe& b) const { return !(*this == b); }
 };
 
-// a in [0, 2p), limbs normalised  ->  a mod p
+// a in [0, 2M), limbs normalised -> a - M if a >= M   (M = p or 2p, given as limbs)
 template <class P>
-BPP_HD void fe_cond_sub_p(Fe<P>& a) {
+BPP_HD void fe_cond_sub(Fe<P>& a, const uint32_t* M) {
     constexpr int NL = P::NL;
     uint32_t d[NL];
     int32_t borrow = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        int32_t t = (int32_t)a.l[i] - (int32_t)P::MOD[i] + borrow;
+        int32_t t = (int32_t)a.l[i] - (int32_t)M[i] + borrow;
         d[i] = (uint32_t)t & LIMB_MASK;
         borrow = t >> LIMB_BITS;  // 0 or -1
     }
@@ -85,7 +87,13 @@ BPP_HD void fe_cond_sub_p(Fe<P>& a) {
 #pragma unroll
     for (int i = 0; i < NL; i++) a.l[i] = take ? d[i] : a.l[i];
 }
+// [0, 2p) -> [0, p)
+template <class P>
+BPP_HD void fe_cond_sub_p(Fe<P>& a) {
+    fe_cond_sub<P>(a, P::MOD);
+}
 
+// a, b in [0, 2p) -> a + b mod p in [0, 2p)
 template <class P>
 BPP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
     constexpr int NL = P::NL;
@@ -97,11 +105,12 @@ BPP_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
         r.l[i] = t & LIMB_MASK;
         c = t >> LIMB_BITS;
     }
-    // a + b < 2p < 2^(30 NL): no carry out of the top limb
-    fe_cond_sub_p(r);
+    // a + b < 4p < 2^(30 NL): no carry out of the top limb
+    fe_cond_sub<P>(r, P::MOD2);
     return r;
 }
 
+// a, b in [0, 2p) -> a - b mod p in [0, 2p)
 template <class P>
 BPP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     constexpr int NL = P::NL;
@@ -113,15 +122,20 @@ BPP_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
         r.l[i] = (uint32_t)t & LIMB_MASK;
         borrow = t >> LIMB_BITS;
     }
-    const uint32_t mask = (uint32_t)borrow;  // all ones when a < b
+    const uint32_t mask = (uint32_t)borrow;  // all ones when a < b: add 2p
     uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        uint32_t t = r.l[i] + (P::MOD[i] & mask) + c;
+        uint32_t t = r.l[i] + (P::MOD2[i] & mask) + c;
         r.l[i] = t & LIMB_MASK;
         c = t >> LIMB_BITS;
     }
     return r;
+}
+
+template <class P>
+BPP_HD bool Fe<P>::operator==(const Fe<P>& b) const {
+    return fe_sub(*this, b).is_zero();
 }
 
 template <class P>
@@ -160,8 +174,8 @@ BPP_HD Fe<P> fe_mont_reduce(const uint32_t* T) {
         r.l[k - NL] = (uint32_t)acc & LIMB_MASK;
         acc >>= LIMB_BITS;
     }
-    // (T + m p) / R < 2p < 2^(30 NL)  =>  acc == 0 here
-    fe_cond_sub_p(r);
+    // (T + m p) / R < T / R + p, which is < 2p for every caller (products of values < 2p: T < 4 p^2 and
+    // 4p < R)  =>  acc == 0 here and the result already satisfies the [0, 2p) invariant
     return r;
 }
 
@@ -276,7 +290,8 @@ BPP_HD void fe_to_canonical(const Fe<P>& a, uint32_t* w) {
     for (int i = 0; i < P::NL; i++) T[i] = a.l[i];
 #pragma unroll
     for (int i = P::NL; i < 2 * P::NL; i++) T[i] = 0;
-    Fe<P> t = fe_mont_reduce<P>(T);
+    Fe<P> t = fe_mont_reduce<P>(T);   // < a / R + p < 2p
+    fe_cond_sub_p(t);
     fe_pack(t, w);
 }
 
@@ -287,7 +302,9 @@ BPP_HD Fe<P> fe_load(const uint32_t* w) {
 }
 template <class P>
 BPP_HD void fe_store(const Fe<P>& a, uint32_t* w) {
-    fe_pack(a, w);
+    Fe<P> t = a;
+    fe_cond_sub_p(t);   // the memory image is the fully reduced value (2p need not fit in N words)
+    fe_pack(t, w);
 }
 
 template <class P>

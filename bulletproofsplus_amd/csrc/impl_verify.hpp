@@ -17,13 +17,20 @@ struct bpp_verifier {
     bpp::DevBuf table;       // window tables
     bpp::DevBuf challenges;  // default challenges
     size_t table_bytes = 0;
-    // optional per-stage HIP-event timing (recorded on the caller's stream)
+    // optional per-stage HIP-event timing: one (begin, end) event pair per stage and remembered pass
     bool profiling = false;
-    std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x (BPP_NUM_STAGES + 1)
+    std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x BPP_NUM_STAGES x 2
     size_t passes_recorded = 0;
     unsigned last_blocks_per_proof = 0;
+    // the proof-point kernels run on a side stream, beside the fixed-generator MSM (their last stage, one
+    // lane per proof, is latency bound and would otherwise leave the chip idle)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~bpp_verifier() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -118,6 +125,13 @@ struct VerifyImpl {
             delete v;
             return fail(BPP_E_HIP, std::string("table build failed: ") + hipGetErrorString(e));
         }
+        e = hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            delete v;
+            return fail(BPP_E_HIP, std::string("stream/event creation failed: ") + hipGetErrorString(e));
+        }
         *out = v;
         return BPP_OK;
     }
@@ -138,36 +152,49 @@ struct VerifyImpl {
         uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
         const unsigned bpp_ = blocks_per_proof(s, count);
         const size_t npts = count * s.NV;
-        hipEvent_t* ev = nullptr;
+        hipEvent_t* ev = nullptr;   // ev[2 * stage], ev[2 * stage + 1]
         if (v->profiling) {
-            ev = v->events.data() + (v->passes_recorded % BPP_PROFILE_SLOTS) * (BPP_NUM_STAGES + 1);
+            ev = v->events.data() + (v->passes_recorded % BPP_PROFILE_SLOTS) * (BPP_NUM_STAGES * 2);
             v->passes_recorded++;
         }
+        auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
         v->last_blocks_per_proof = bpp_;
+        hipStream_t sd = v->side;
         HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
-        if (ev) HIPCHK(hipEventRecord(ev[0], st));
+        HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
         hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
                            reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
+        HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
         const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
         const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
-        if (ev) HIPCHK(hipEventRecord(ev[1], st));
+        HIPCHK(mark(2 * BPP_STAGE_SCALARS, st));
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
-        if (ev) HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
-                           s, w_sc, v->table.u32(), w_fp, bpp_);
-        if (ev) HIPCHK(hipEventRecord(ev[3], st));
+        HIPCHK(mark(2 * BPP_STAGE_SCALARS + 1, st));
+        // fork: proof-point part on the side stream
+        HIPCHK(hipEventRecord(v->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(sd, v->ev_fork, 0));
         uint8_t* w_vd = ws + L.vdig;
         uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
         const size_t vlanes = count * VAR_WINDOWS;
-        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts);
-        hipLaunchKernelGGL(k_var_buckets<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_pts, w_vt,
+        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, sd));
+        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, sd, s, w_sc, w_vd, npts);
+        hipLaunchKernelGGL(k_var_buckets<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, s, w_vd, w_pts, w_vt,
                            w_vw, vlanes);
-        hipLaunchKernelGGL(k_var_horner<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_vw, w_vp, count);
-        if (ev) HIPCHK(hipEventRecord(ev[4], st));
+        hipLaunchKernelGGL(k_var_horner<C>, dim3(cdiv(count, 64)), dim3(64), 0, sd, w_vw, w_vp, count);
+        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, sd));
+        HIPCHK(hipEventRecord(v->ev_join, sd));
+        // fixed-generator part on the caller's stream
+        HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
+                           s, w_sc, v->table.u32(), w_fp, bpp_);
+        HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
+        // join
+        HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
+        HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
         hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
-        if (ev) HIPCHK(hipEventRecord(ev[5], st));
+        HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }
