@@ -345,7 +345,9 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     const size_t nb = (size_t)s.W * s.half;
     hipLaunchKernelGGL(k_pip_buckets<C>, dim3((unsigned)((nb + 127) / 128)), dim3(128), 0, st, s, d_points, sorted,
                        offsets, counts, buckets, hlist, hcount);
-    const unsigned hgrid = (unsigned)std::min<size_t>(w.max_heavy, 2048);
+    // heavy buckets are few (none at all for uniformly distributed digits): a small grid that strides over
+    // the list -- an oversized grid of immediately-exiting blocks costs milliseconds
+    const unsigned hgrid = (unsigned)std::min<size_t>(w.max_heavy, 64);
     hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * JW * 4, st, s, d_points, sorted,
                        offsets, counts, hlist, hcount, hparts);
     hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3((hgrid + 63) / 64), dim3(64), 0, st, hlist, hcount, hparts, buckets);
