@@ -259,7 +259,7 @@ struct VerifyImpl {
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st, s,
+        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st, s,
                            w_cs, v->table.u32(), w_fp, L.fixed_blocks);
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
         HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
@@ -313,7 +313,7 @@ struct VerifyImpl {
                                    d_cG.u32(), d_cH.u32(), d_pwy.u32(), d_con.u32(), d_vps.u32());
             hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
                                d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
-            hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
+            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
                                FIXED_BLOCK * JW * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per);
             hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
                                d_pts.u32(), d_V.u32(), nv_total);

@@ -590,7 +590,8 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // scalar + bias -> W unsigned windows -> signed digits in [-half, half) -> one table gather and one mixed
 // addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
 // that.  partials: [count][per] jacobians.
-template <class C>
+// ROLE only separates the launches in profiles: 0 = the batch verifier's hot path, 1 = prover / combined check.
+template <class C, int ROLE = 0>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per) {
     constexpr int N = C::Fp::N;
