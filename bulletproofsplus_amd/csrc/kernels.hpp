@@ -15,7 +15,7 @@
 //   k_jac_reduce         sums jacobian partials of one MulVec -> wire point
 //   k_verify_scalars     all verifier scalars of one proof      wip.rs:330-382, range/mod.rs:417-477, :198-226,
 //                                                               wip.rs:254-295
-//   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables
+//   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums)
 //                                                               range/mod.rs:480-503 / wip.rs:297-320
 //   k_var_digits/buckets/horner  the 3+2k+m proof-dependent terms of the same MulVec (bucket method per proof)
 //   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327

@@ -420,9 +420,13 @@ class Transcript:
     Y_SINGLE, Z_SINGLE = 7, 7      # range/mod.rs:109-110, :198-199
     Y_MULTI, Z_MULTI = 12, 23      # range/mod.rs:278-279, :417-418
     D_L, D_R = 4, 5       # wip.rs:94-95
-    E_ROUND = 7           # wip.rs:131, :353
+    E_ROUND = 7           # wip.rs:131, :353 ; tests may set a list (one challenge per round)
     R, S, DELTA, ETA = 33, 44, 88, 123   # wip.rs:175-178
     E_FINAL = 99          # wip.rs:211, :369
+
+    @classmethod
+    def e_round(cls, i):
+        return cls.E_ROUND[i] if isinstance(cls.E_ROUND, (list, tuple)) else cls.E_ROUND
 
 
 # --------------------------------------------------------------------------------------
@@ -477,7 +481,7 @@ class WeightedInnerProductProof:
             L_vec.append(L)
             R_vec.append(R)
 
-            e = F.new(T.E_ROUND)
+            e = F.new(T.e_round(len(L_vec) - 1))
             e_inv = F.inv(e)
             e_sqr = e * e % r
             e_sqr_inv = e_inv * e_inv % r
@@ -526,7 +530,7 @@ class WeightedInnerProductProof:
         logn = len(self.L_vec)
         if n != (1 << logn):
             return None
-        challenges = [F.new(Transcript.E_ROUND) for _ in range(logn)]
+        challenges = [F.new(Transcript.e_round(i)) for i in range(logn)]
         allinv, challenges_inv = F.batch_invert(challenges)
         challenges_sqr = [c * c % r for c in challenges]
         challenges_inv_sqr = [c * c % r for c in challenges_inv]

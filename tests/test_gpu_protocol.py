@@ -389,3 +389,74 @@ def test_full_size_batch_round_trip_properties():
         assert run_combined_device(torch, eng, dirty_recs, dirty_sc, 3 + c)[0] == 1
         eng.close()
     assert verdicts[0] == verdicts[1]
+
+
+@pytest.mark.parametrize("cname,n,vals,gams", [("bls12_381", 8, [200, 5], [3, 7]), ("secp256k1", 8, [77], [9]),
+                                               ("ed25519", 4, [9, 3, 15, 0], [1, 2, 3, 4])])
+def test_arbitrary_per_proof_challenges(cname, n, vals, gams, monkeypatch):
+    """The verifier is not tied to the reference's constant "transcript": with full-width per-proof
+    challenges (y, z, e, one e_t per round) supplied through d_challenges, the MulVec scalars, result and
+    verdict equal the big-integer restatement run with the same challenges.  (The reference itself has no
+    transcript; this is the path a Fiat-Shamir front end would use.)"""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    cid = CID[cname]
+    m = len(vals)
+    mn = n * m
+    k = mn.bit_length() - 1
+    r = P.CURVES[cname]["r"]
+    a = B.Arith.init(cid)
+    G = P.make_group(cname, shadow=False)
+    recs, scs, chs, exp_sc, exp_ok = [], [], [], [], []
+    for t in range(3):
+        y = (0x1234567890ABCDEF1234567890ABCDEF * (t + 3) ** 7 + 11) % r
+        z = (0xFEDCBA0987654321FEDCBA0987654321 * (t + 5) ** 5 + 7) % r
+        ef = (0xA5A5A5A5DEADBEEFCAFEBABE12345678 * (t + 2) ** 9 + 3) % r
+        er = [(0x9E3779B97F4A7C15F39CC0605CEDC834 * (i + 2 + t) ** 11 + 1) % r for i in range(k)]
+        for name, val in (("Y_SINGLE", y), ("Z_SINGLE", z), ("Y_MULTI", y), ("Z_MULTI", z), ("E_FINAL", ef), ("E_ROUND", er)):
+            monkeypatch.setattr(P.Transcript, name, val)
+        pk = P.PublicKey(G, mn)
+        pr = P.RangeProver()
+        for v, g in zip(vals, gams):
+            pr.commit(pk, v, g + t)
+        proof = P.RangeProof.prove(pk, n, pr)
+        mv = proof.verify_mulvec(pk, n, pr.commitment_vec)
+        exp_ok.append(0 if proof.verify(pk, n, pr.commitment_vec) else 1)
+        exp_sc.append(mv.scalars)
+        pts = [proof.A, proof.proof.A, proof.proof.B] + proof.proof.L_vec + proof.proof.R_vec + pr.commitment_vec
+        recs.append(O.points_to_wire(cid, pts))
+        scs.append(O.scalars_to_wire([proof.proof.r_prime, proof.proof.s_prime, proof.proof.d_prime]))
+        chs.append(O.scalars_to_wire([y, z, ef] + er))
+    assert exp_ok == [0, 0, 0]
+    ppk = P.PublicKey(G, mn)
+    pk = B.PublicKey.from_points(a, O.points_to_wire(cid, [ppk.g, ppk.h]), O.points_to_wire(cid, ppk.G_vec),
+                                 O.points_to_wire(cid, ppk.H_vec))
+    bv = B.BatchVerifier(pk, n, m, window_bits=5)
+    ok, got_sc, got_res = run_verifier_device(torch, bv, np.stack(recs), np.stack(scs), challenges=np.stack(chs))
+    assert ok.tolist() == [0, 0, 0]
+    for t in range(3):
+        assert O.wire_to_scalars(got_sc[t]) == exp_sc[t], t
+    # the same proofs under the reference's constants (or each other's challenges) do not verify
+    ok2, _, _ = run_verifier_device(torch, bv, np.stack(recs), np.stack(scs))
+    assert ok2.tolist() == [1, 1, 1]
+    ok3, _, _ = run_verifier_device(torch, bv, np.stack(recs), np.stack(scs), challenges=np.stack(chs[::-1]))
+    assert ok3.tolist() == [1, 0, 1]
+
+
+def test_secp256k1_reference_size_against_oracle():
+    """secp256k1 at n = 64, m = 4 (mn = 256): batched prover == C oracle prover, verifier scalars == oracle."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init("secp256k1")
+    opk = O.PublicKey(O.SECP256K1, 256)
+    pk = B.PublicKey.new(a, 256)
+    assert np.array_equal(pk.G_vec, opk.G)
+    vals, gams = [31, 2**31 - 1, 0, 123456789], [7, 8, 9, 10]
+    opts, osc, oV = O.range_prove(opk, 64, vals, gams)
+    eng = B.BatchVerifier(pk, 64, 4, window_bits=9)
+    pts, sc, V = eng.prove_batch([vals], [gams])
+    assert np.array_equal(pts[0], opts) and np.array_equal(sc[0], osc) and np.array_equal(V[0], oV)
+    rc, exp_sc, _ = O.range_verify(opk, 64, 4, opts, osc, oV, want_scalars=True, skip_msm=True)
+    rec = np.concatenate([opts, oV])[None]
+    ok, got_sc, got_res = run_verifier_device(torch, eng, rec, osc[None])
+    assert ok.tolist() == [0] and np.array_equal(got_sc[0], exp_sc) and a.is_zero(got_res[0])
