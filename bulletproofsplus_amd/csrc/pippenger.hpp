@@ -28,6 +28,7 @@ namespace bpp {
 struct PipShape {
     uint32_t n;                // points
     uint32_t c, W, half;       // window bits, windows, buckets per window 2^(c-1)
+    uint32_t heavy;            // a bucket with more points than this is split over many lanes
     uint32_t bias[10];         // sum_j half * 2^(c j)
 };
 
@@ -37,6 +38,8 @@ inline PipShape pip_shape(size_t n, int c) {
     s.c = (uint32_t)c;
     s.W = (258 + c - 1) / c;
     s.half = 1u << (c - 1);
+    // heavy = far above the load of a uniformly filled window (n / half points per bucket)
+    s.heavy = (uint32_t)std::max<size_t>(96, 6 * (n / s.half + 1));
     for (int t = 0; t < 10; t++) s.bias[t] = 0;
     for (uint32_t j = 0; j < s.W; j++) {
         const uint32_t bit = s.c * j + (s.c - 1);
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32
     if (gid >= (size_t)s.W * s.half) return;
     const uint32_t j = (uint32_t)(gid / s.half);
     const uint32_t beg = offsets[gid], cnt = counts[gid];
-    if (cnt > PIP_HEAVY) {
+    if (cnt > s.heavy) {
         heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)gid;
         return;
     }
@@ -206,21 +209,23 @@ __global__ void __launch_bounds__(128, 2) k_pip_heavy(PipShape s, const uint32_t
     }
 }
 
-// one lane per heavy bucket: bucket = sum of its PIP_SPLIT parts
+// one block of PIP_SPLIT lanes per heavy bucket: bucket = sum of its PIP_SPLIT parts (LDS tree)
 template <class C>
-__global__ void __launch_bounds__(64) k_pip_heavy_fold(const uint32_t* __restrict__ heavy_list,
-                                                       const uint32_t* __restrict__ heavy_count,
-                                                       const uint32_t* __restrict__ heavy_parts,
-                                                       uint32_t* __restrict__ buckets) {
+__global__ void __launch_bounds__(PIP_SPLIT) k_pip_heavy_fold(const uint32_t* __restrict__ heavy_list,
+                                                              const uint32_t* __restrict__ heavy_count,
+                                                              const uint32_t* __restrict__ heavy_parts,
+                                                              uint32_t* __restrict__ buckets) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
+    extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t nheavy = *heavy_count;
-    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nheavy; h += gridDim.x * blockDim.x) {
-        Jac<C> acc = jac_inf<C>();
-        for (uint32_t t = 0; t < PIP_SPLIT; t++)
-            acc = jac_add(acc, jac_ldg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + t) * JW));
-        jac_stg<C>(buckets + (size_t)heavy_list[h] * JW, acc);
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        Jac<C> acc = jac_ldg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + threadIdx.x) * JW);
+        acc = block_reduce_jac<C>(acc, lds);
+        if (threadIdx.x == 0) jac_stg<C>(buckets + (size_t)heavy_list[h] * JW, acc);
+        __syncthreads();
     }
+    (void)N;
 }
 
 // one block per window: R_j = sum_b (b + 1) * B_b.  Thread t owns the segment [t*S, (t+1)*S) with
@@ -306,8 +311,8 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     o += al((size_t)s.W * s.half * JW * 4);
     w.wsums = o;
     o += al((size_t)s.W * JW * 4);
-    // a heavy bucket holds > PIP_HEAVY of the W * n sorted entries
-    w.max_heavy = std::min<size_t>((size_t)s.W * s.half, (size_t)s.W * s.n / PIP_HEAVY + 1);
+    // a heavy bucket holds > s.heavy of the W * n sorted entries
+    w.max_heavy = std::min<size_t>((size_t)s.W * s.half, (size_t)s.W * s.n / s.heavy + 1);
     w.hlist = o;
     o += al(w.max_heavy * 4);
     w.hcount = o;
@@ -350,7 +355,8 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     const unsigned hgrid = (unsigned)std::min<size_t>(w.max_heavy, 64);
     hipLaunchKernelGGL(k_pip_heavy<C>, dim3(hgrid, PIP_SPLIT), dim3(128), 128 * JW * 4, st, s, d_points, sorted,
                        offsets, counts, hlist, hcount, hparts);
-    hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3((hgrid + 63) / 64), dim3(64), 0, st, hlist, hcount, hparts, buckets);
+    hipLaunchKernelGGL(k_pip_heavy_fold<C>, dim3(hgrid), dim3(PIP_SPLIT), PIP_SPLIT * JW * 4, st, hlist, hcount, hparts,
+                       buckets);
     // 512 lanes x 144 B of LDS exceed the 64 KB default for dynamic LDS: opt in (160 KB per CU on gfx950)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pip_windows<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(PIP_WIN_BLOCK * JW * 4));
