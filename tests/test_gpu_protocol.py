@@ -460,3 +460,33 @@ def test_secp256k1_reference_size_against_oracle():
     rec = np.concatenate([opts, oV])[None]
     ok, got_sc, got_res = run_verifier_device(torch, eng, rec, osc[None])
     assert ok.tolist() == [0] and np.array_equal(got_sc[0], exp_sc) and a.is_zero(got_res[0])
+
+
+def test_maximum_supported_shape_round_trip():
+    """n = 64, m = 64 (mn = 4096, k = 12, 8 285 MulVec terms, 91 proof points): the largest shape the engine
+    accepts.  Exercises the > 64 KB dynamic-LDS path of k_verify_scalars and NV > 64 in the proof-point
+    kernels.  Round trip + tamper + combined check; shapes beyond the limit are usage errors."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, 4096)
+    eng = B.BatchVerifier(pk, 64, 64, window_bits=8)
+    assert eng.msm_len == 2 * 4096 + 24 + 64 + 5 and eng.points_per_proof == 91
+    rnd = np.random.RandomState(9)
+    vals = rnd.randint(0, 2**31 - 1, size=(3, 64)).astype(np.uint64)
+    gams = [[int(x) for x in row] for row in rnd.randint(1, 2**62, size=(3, 64))]
+    pts, sc, V = eng.prove_batch(vals, gams)
+    recs = np.concatenate([pts, V], axis=1)
+    assert eng.verify_wire(recs, sc).tolist() == [0, 0, 0]
+    bad = sc.copy()
+    bad[1, 0, 2] ^= 1
+    assert eng.verify_wire(recs, bad).tolist() == [0, 1, 0]
+    assert run_combined_device(torch, eng, recs, sc, 1)[0] == 0
+    assert run_combined_device(torch, eng, recs, bad, 1)[0] == 1
+    # shadow known answer for the first proof's scalars (group independent)
+    _, _, sproof = P.prove_case("bls12_381", 64, [int(x) for x in vals[0]], gams[0], shadow=True)
+    assert O.wire_to_scalars(sc[0]) == [sproof.proof.r_prime, sproof.proof.s_prime, sproof.proof.d_prime]
+    with pytest.raises(B.BppError):
+        B.BatchVerifier(B.PublicKey.new(a, 24), 8, 3, window_bits=8)       # n*m not a power of two
+    with pytest.raises(B.BppError):
+        B.BatchVerifier(pk, 64, 64, window_bits=40)                         # window out of range
