@@ -179,7 +179,7 @@ BPP_HD Jac<C> jac_add(const Jac<C>& p, const Jac<C>& q) {
     F V = fe_mul(U1, I);
     Jac<C> r;
     r.X = fe_sub(fe_sub(fe_sqr(rr), J), fe_dbl(V));
-    r.Y = fe_sub(fe_mul(rr, fe_sub(V, r.X)), fe_dbl(fe_mul(S1, J)));
+    r.Y = fe_mul_add(rr, fe_sub(V, r.X), fe_neg(fe_dbl(S1)), J);   // rr (V - X3) - 2 S1 J, one reduction
     F zz = fe_sqr(fe_add(p.Z, q.Z));
     r.Z = fe_mul(fe_sub(fe_sub(zz, Z1Z1), Z2Z2), H);
     return r;
@@ -207,7 +207,7 @@ BPP_HD Jac<C> jac_madd(const Jac<C>& p, const Aff<C>& q) {
     F V = fe_mul(p.X, I);
     Jac<C> r;
     r.X = fe_sub(fe_sub(fe_sqr(rr), J), fe_dbl(V));
-    r.Y = fe_sub(fe_mul(rr, fe_sub(V, r.X)), fe_dbl(fe_mul(p.Y, J)));
+    r.Y = fe_mul_add(rr, fe_sub(V, r.X), fe_neg(fe_dbl(p.Y)), J);   // rr (V - X3) - 2 Y1 J, one reduction
     F zh = fe_sqr(fe_add(p.Z, H));
     r.Z = fe_sub(fe_sub(zh, Z1Z1), HH);
     return r;
@@ -255,7 +255,7 @@ BPP_HD Xyzz<C> xyzz_dbl_aff(const Aff<C>& q) {
     F M = fe_add(fe_dbl(xx), xx);
     Xyzz<C> r;
     r.X = fe_sub(fe_sqr(M), fe_dbl(S));
-    r.Y = fe_sub(fe_mul(M, fe_sub(S, r.X)), fe_mul(W, q.y));
+    r.Y = fe_mul_add(M, fe_sub(S, r.X), fe_neg(W), q.y);   // M (S - X3) - W y, one reduction
     r.ZZ = V;
     r.ZZZ = W;
     return r;
@@ -286,7 +286,7 @@ BPP_HD Xyzz<C> xyzz_madd(const Xyzz<C>& p, const Aff<C>& q) {
     F Q = fe_mul(p.X, PP);
     Xyzz<C> r;
     r.X = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
-    r.Y = fe_sub(fe_mul(R, fe_sub(Q, r.X)), fe_mul(p.Y, PPP));
+    r.Y = fe_mul_add(R, fe_sub(Q, r.X), fe_neg(p.Y), PPP);   // R (Q - X3) - Y1 PPP, one reduction
     r.ZZ = fe_mul(p.ZZ, PP);
     r.ZZZ = fe_mul(p.ZZZ, PPP);
     return r;

@@ -179,11 +179,10 @@ BPP_HD Fe<P> fe_mont_reduce(const uint32_t* T) {
     return r;
 }
 
-// Montgomery product a*b*R^-1 mod p: NL^2 v_mad_u64_u32 for the product, NL^2 + NL for the reduction.
+// Plain product a*b as 2 NL normalised limbs (NL^2 v_mad_u64_u32)
 template <class P>
-BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+BPP_HD void fe_mul_wide(const Fe<P>& a, const Fe<P>& b, uint32_t* T) {
     constexpr int NL = P::NL;
-    uint32_t T[2 * NL];
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
@@ -194,15 +193,37 @@ BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
         acc >>= LIMB_BITS;
     }
     T[2 * NL - 1] = (uint32_t)acc;
+}
+
+// Montgomery product a*b*R^-1 mod p: NL^2 v_mad_u64_u32 for the product, NL^2 + NL for the reduction.
+template <class P>
+BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t T[2 * P::NL];
+    fe_mul_wide(a, b, T);
     return fe_mont_reduce<P>(T);
 }
 
-// Montgomery square: the NL(NL-1)/2 cross products are computed once and doubled.
+// (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: the two double-width products are added limb by
+// limb (each limb < 2^31, which the reduction's column accumulator absorbs) and reduced together.  For
+// operands < 2p the sum is < 8 p^2, and 8p / R < 1/32 for every field here, so the result is < 1.04 p: the
+// [0, 2p) invariant holds.  Saves NL^2 + NL of the 3 NL^2 + NL multiplier operations of two separate products.
+template <class P>
+BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
+    constexpr int NL = P::NL;
+    uint32_t T[2 * NL], U[2 * NL];
+    fe_mul_wide(a, b, T);
+    fe_mul_wide(c, d, U);
+#pragma unroll
+    for (int i = 0; i < 2 * NL; i++) T[i] += U[i];
+    return fe_mont_reduce<P>(T);
+}
+
+// Montgomery square: the NL(NL-1)/2 cross products are computed once, against a pre-doubled copy of the
+// operand (2 a_j < 2^31, so a column of <= 6 cross products + 1 square stays below 2^64), in ONE running
+// column accumulator exactly like fe_mul: 91 v_mad_u64_u32 instead of 169 for the product phase.
 template <class P>
 BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
 #if defined(BPP_SQR_OPAQUE) && defined(__HIP_DEVICE_COMPILE__)
-    // hide from the compiler that both operands are equal: it otherwise merges a_i*a_j with a_j*a_i into
-    // a doubled half-product schedule that issues fewer v_mad_u64_u32 but runs slower (profiles/ubench)
     Fe<P> b = a;
 #pragma unroll
     for (int i = 0; i < P::NL; i++) asm volatile("" : "+v"(b.l[i]));
@@ -211,21 +232,21 @@ BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
     return fe_mul(a, a);
 #endif
     constexpr int NL = P::NL;
+    uint32_t a2[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
     uint32_t T[2 * NL];
-    uint64_t carry = 0;
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
-        uint64_t acc = 0;
         // pairs i < j, i + j = k
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (uint64_t)a.l[i] * a.l[k - i];
-        acc <<= 1;  // <= 6 * 2^60 * 2 < 2^64
+        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (uint64_t)a.l[i] * a2[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-        acc += carry;
         T[k] = (uint32_t)acc & LIMB_MASK;
-        carry = acc >> LIMB_BITS;
+        acc >>= LIMB_BITS;
     }
-    T[2 * NL - 1] = (uint32_t)carry;
+    T[2 * NL - 1] = (uint32_t)acc;
     return fe_mont_reduce<P>(T);
 }
 
@@ -323,16 +344,193 @@ BPP_HD Fe<P> fe_from_i32(int32_t n) {
     return fe_neg(fe_from_u32<P>((uint32_t)(-(int64_t)n)));
 }
 
-// a^(p-2) by square-and-multiply over the bits of p-2 (a = 0 -> 0).  Same field element as the
-// reference's Fr::inv (mcl) / ext-Euclid safe_inv (field/prime_field_elem.rs:339-392).
+// a^(p-2) by square-and-multiply over the bits of p-2 (a = 0 -> 0): ~1.5 BITS Montgomery products.  Kept
+// as the independent cross-check of fe_inv (tests/host/field_host_test.cpp, tools/ubench.hip).
 template <class P>
-BPP_HD Fe<P> fe_inv(const Fe<P>& a) {
+BPP_HD Fe<P> fe_inv_fermat(const Fe<P>& a) {
     Fe<P> acc = Fe<P>::one();
     for (int i = P::BITS - 1; i >= 0; i--) {
         acc = fe_sqr(acc);
         if ((P::PM2[i >> 5] >> (i & 31)) & 1u) acc = fe_mul(acc, a);
     }
     return acc;
+}
+
+// Modular inverse by the Bernstein-Yang "safegcd" division steps (half-delta variant), arranged for this
+// library's 30-bit limbs: 30 divsteps are run on the low words of (f, g) alone and collected in a 2x2
+// transition matrix t = [[u, v], [q, r]] (entries < 2^30 in magnitude); t is then applied to the full-width
+// (f, g) -- an exact division by 2^30 -- and to the Bezout pair (d, e) modulo p.  P::INV_BATCHES batches make
+// g = 0 and f = +-1 for every input, so there is no data-dependent control flow: all 64 lanes of a wave run
+// the same instructions.  Cost on gfx950: ~30 batches x (600 32-bit ops + 130 v_mad_i64_i32) for the 381-bit
+// field, i.e. about 26 Montgomery products instead of the ~570 of Fermat's little theorem.
+// Same field element as the reference's Fr::inv (mcl) / ext-Euclid safe_inv
+// (field/prime_field_elem.rs:339-392); a = 0 -> 0.
+namespace safegcd {
+
+// value = sum v[i] 2^(30 i); limbs 0..NL-2 in [0, 2^30), top limb signed
+template <int NL>
+struct S30 {
+    int32_t v[NL];
+};
+
+struct Trans {
+    int32_t u, v, q, r;
+};
+
+// 30 half-delta divsteps on the low words.  zeta = -(delta + 1/2).
+BPP_HD int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, Trans& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    uint32_t f = f0, g = g0;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+        uint32_t c1 = (uint32_t)(zeta >> 31);     // all ones iff delta > 0
+        const uint32_t c2 = 0u - (g & 1u);        // all ones iff g is odd
+        const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // (f, u, v) or their negation
+        g += x & c2;
+        q += y & c2;
+        r += z & c2;
+        c1 &= c2;                                 // swap: delta > 0 and g odd
+        zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
+        f += g & c1;
+        u += q & c1;
+        v += r & c1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return zeta;
+}
+
+// signed 32 x 32 -> 64 product.  The limb operand is passed through an empty asm so that the compiler forgets
+// it is a masked (non-negative) value: otherwise it widens signed x unsigned to a 64 x 32 multiply
+// (v_mad_u64_u32 + v_mul_lo_u32) instead of one v_mad_i64_i32.
+BPP_HD int64_t mul32(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(b));
+#endif
+    return (int64_t)a * (int64_t)b;
+}
+
+// (f, g) <- t (f, g) / 2^30   (the division is exact)
+template <int NL>
+BPP_HD void update_fg(S30<NL>& f, S30<NL>& g, const Trans& t) {
+    int64_t cf = mul32(t.u, f.v[0]) + mul32(t.v, g.v[0]);
+    int64_t cg = mul32(t.q, f.v[0]) + mul32(t.r, g.v[0]);
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < NL; i++) {
+        const int32_t fi = f.v[i], gi = g.v[i];
+        cf += mul32(t.u, fi) + mul32(t.v, gi);
+        cg += mul32(t.q, fi) + mul32(t.r, gi);
+        f.v[i - 1] = (int32_t)((uint32_t)cf & LIMB_MASK);
+        g.v[i - 1] = (int32_t)((uint32_t)cg & LIMB_MASK);
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f.v[NL - 1] = (int32_t)cf;
+    g.v[NL - 1] = (int32_t)cg;
+}
+
+// (d, e) <- t (d, e) / 2^30 mod p, both kept in (-2p, p): a multiple of p is added first to make the
+// combination non-negative-ish, then the multiple that clears the low 30 bits.
+template <class P>
+BPP_HD void update_de(S30<P::NL>& d, S30<P::NL>& e, const Trans& t) {
+    constexpr int NL = P::NL;
+    const int32_t sd = d.v[NL - 1] >> 31, se = e.v[NL - 1] >> 31;
+    int32_t md = (t.u & sd) + (t.v & se);
+    int32_t me = (t.q & sd) + (t.r & se);
+    int64_t cd = mul32(t.u, d.v[0]) + mul32(t.v, e.v[0]);
+    int64_t ce = mul32(t.q, d.v[0]) + mul32(t.r, e.v[0]);
+    md -= (int32_t)((P::PINV * (uint32_t)cd + (uint32_t)md) & LIMB_MASK);
+    me -= (int32_t)((P::PINV * (uint32_t)ce + (uint32_t)me) & LIMB_MASK);
+    cd += mul32((int32_t)P::MOD[0], md);
+    ce += mul32((int32_t)P::MOD[0], me);
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < NL; i++) {
+        const int32_t di = d.v[i], ei = e.v[i];
+        cd += mul32(t.u, di) + mul32(t.v, ei) + mul32((int32_t)P::MOD[i], md);
+        ce += mul32(t.q, di) + mul32(t.r, ei) + mul32((int32_t)P::MOD[i], me);
+        d.v[i - 1] = (int32_t)((uint32_t)cd & LIMB_MASK);
+        e.v[i - 1] = (int32_t)((uint32_t)ce & LIMB_MASK);
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d.v[NL - 1] = (int32_t)cd;
+    e.v[NL - 1] = (int32_t)ce;
+}
+
+// r in (-2p, p) -> [0, p), negated first when `neg` (f ended at -1)
+template <class P>
+BPP_HD void normalize(S30<P::NL>& r, int32_t neg) {
+    constexpr int NL = P::NL;
+    int32_t add = r.v[NL - 1] >> 31;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        int32_t x = r.v[i] + ((int32_t)P::MOD[i] & add);
+        r.v[i] = (x ^ neg) - neg;
+    }
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        r.v[i + 1] += r.v[i] >> 30;
+        r.v[i] &= (int32_t)LIMB_MASK;
+    }
+    add = r.v[NL - 1] >> 31;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] += (int32_t)P::MOD[i] & add;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        r.v[i + 1] += r.v[i] >> 30;
+        r.v[i] &= (int32_t)LIMB_MASK;
+    }
+}
+
+}  // namespace safegcd
+
+// x^-1 mod p for a plain (non-Montgomery) residue given as normalised limbs of a value in [0, p)
+template <class P>
+BPP_HD Fe<P> fe_inv_plain(const Fe<P>& x) {
+    constexpr int NL = P::NL;
+    safegcd::S30<NL> d, e, f, g;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        d.v[i] = 0;
+        e.v[i] = i == 0 ? 1 : 0;
+        f.v[i] = (int32_t)P::MOD[i];
+        g.v[i] = (int32_t)x.l[i];
+    }
+    int32_t zeta = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int it = 0; it < P::INV_BATCHES; it++) {
+        safegcd::Trans t;
+        zeta = safegcd::divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        safegcd::update_de<P>(d, e, t);
+        safegcd::update_fg<NL>(f, g, t);
+    }
+    safegcd::normalize<P>(d, f.v[NL - 1] >> 31);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.l[i] = (uint32_t)d.v[i];
+    return r;
+}
+
+// Montgomery form in, Montgomery form out: (aR)^-1 = a^-1 R^-1, times R^3 / R = a^-1 R.
+template <class P>
+BPP_HD Fe<P> fe_inv(const Fe<P>& a) {
+    Fe<P> t = a;
+    fe_cond_sub_p(t);
+    Fe<P> r3;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) r3.l[i] = P::R3[i];
+    return fe_mul(fe_inv_plain(t), r3);
 }
 
 // a^n for a small exponent (reference src/util.rs:39-52 scalar_exp_vartime)

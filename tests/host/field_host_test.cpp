@@ -1,6 +1,6 @@
 // Host-side harness for csrc/field.hpp and csrc/ec.hpp (compiled with g++, no GPU needed).
 // Reads lines:  <field> <op> <hex a> [<hex b>]   and prints the canonical hex result.
-// Fields: blsfp blsfr secpfp secpfr.  Ops: mul sqr add sub neg inv tocanon(roundtrip) pow5
+// Fields: blsfp blsfr secpfp secpfr edfp edfr.  Ops: mul sqr add sub neg inv invf(Fermat) tocanon(roundtrip) pow5
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -31,7 +31,9 @@ template <class P> static void run(const std::string& op, const std::string& ha,
     else if (op == "add") r = fe_add(a, b);
     else if (op == "sub") r = fe_sub(a, b);
     else if (op == "neg") r = fe_neg(a);
+    else if (op == "muladd") r = fe_mul_add(a, b, fe_neg(b), fe_add(a, a));   // a b - 2 a b = -a b, at the 2p bound
     else if (op == "inv") r = fe_inv(a);
+    else if (op == "invf") r = fe_inv_fermat(a);
     else if (op == "pow5") r = fe_pow_u64(a, 5);
     else if (op == "tocanon") { uint32_t m[P::N]; fe_store(a, m); r = fe_load<P>(m); }
     else { printf("bad op\n"); return; }
@@ -48,6 +50,8 @@ int main() {
         else if (f == "blsfr") run<BlsFr>(op, a, b);
         else if (f == "secpfp") run<SecpFp>(op, a, b);
         else if (f == "secpfr") run<SecpFr>(op, a, b);
+        else if (f == "edfp") run<EdFp>(op, a, b);
+        else if (f == "edfr") run<EdFr>(op, a, b);
     }
     return 0;
 }

@@ -50,20 +50,28 @@ def test_host_field_arithmetic_matches_bigints():
     import pyref as P
     exe = os.path.join(tempfile.gettempdir(), "bpp_field_host_test")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "field_host_test.cpp")])
-    mods = {"blsfp": P.BLS12_381["p"], "blsfr": P.BLS12_381["r"], "secpfp": P.SECP256K1["p"], "secpfr": P.SECP256K1["r"]}
+    mods = {"blsfp": P.BLS12_381["p"], "blsfr": P.BLS12_381["r"], "secpfp": P.SECP256K1["p"], "secpfr": P.SECP256K1["r"],
+            "edfp": P.ED25519["p"], "edfr": P.ED25519["r"]}
     rnd = random.Random(3)
     lines, exp = [], []
     for f, m in mods.items():
         vals = [0, 1, 2, m - 1, m - 2, (1 << 64) - 1, (1 << 30) - 1, 1 << 30, (1 << 60) + 1] + [rnd.randrange(m) for _ in range(20)]
         for a in vals:
             for b in vals[:5] + vals[-2:]:
-                for op, fn in (("mul", lambda a, b: a * b % m), ("add", lambda a, b: (a + b) % m), ("sub", lambda a, b: (a - b) % m)):
+                for op, fn in (("mul", lambda a, b: a * b % m), ("add", lambda a, b: (a + b) % m), ("sub", lambda a, b: (a - b) % m),
+                               ("muladd", lambda a, b: -a * b % m)):
                     lines.append("%s %s %x %x" % (f, op, a, b)); exp.append(fn(a, b))
             lines.append("%s sqr %x" % (f, a)); exp.append(a * a % m)
             lines.append("%s neg %x" % (f, a)); exp.append(-a % m)
             lines.append("%s tocanon %x" % (f, a)); exp.append(a)
-            if a:
-                lines.append("%s inv %x" % (f, a)); exp.append(pow(a, -1, m))
+            # safegcd inversion (0 -> 0) and the Fermat cross-check
+            lines.append("%s inv %x" % (f, a)); exp.append(pow(a, -1, m) if a else 0)
+            lines.append("%s invf %x" % (f, a)); exp.append(pow(a, -1, m) if a else 0)
+        # inversion stress: powers of two, values around them, many random residues
+        stress = [1 << k for k in range(0, m.bit_length() - 1, 7)] + [(1 << k) - 1 for k in range(2, m.bit_length() - 1, 11)]
+        stress += [m - (1 << k) for k in range(0, m.bit_length() - 2, 13)] + [rnd.randrange(m) for _ in range(300)]
+        for a in stress:
+            lines.append("%s inv %x" % (f, a % m)); exp.append(pow(a % m, -1, m) if a % m else 0)
         top = (1 << (384 if f == "blsfp" else 256)) - 1
         lines.append("%s mul %x 3" % (f, top)); exp.append(top * 3 % m)
     out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split()

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <vector>
 #include "../bulletproofsplus_amd/csrc/ec.hpp"
+#include "../bulletproofsplus_amd/csrc/ed25519.hpp"
 using namespace bpp;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256) k_inst(uint64_t* out, uint32_t seed) {
     if (s == 0x1234567) out[0] = s;
 }
 
-// kind: 0 fe_mul, 1 fe_sqr, 2 fe_add, 3 fe_sub
+// kind: 0 fe_mul, 1 fe_sqr, 2 fe_add, 3 fe_sub, 4 fe_inv (safegcd), 5 fe_inv_fermat
 template <class P, int KIND>
 __global__ void __launch_bounds__(256) k_field(uint32_t* out, uint32_t seed, int iters) {
     Fe<P> a = fe_from_u32<P>(seed + threadIdx.x + 1), b = fe_from_u32<P>(seed * 7 + blockIdx.x + 3);
@@ -53,11 +54,13 @@ __global__ void __launch_bounds__(256) k_field(uint32_t* out, uint32_t seed, int
         if (KIND == 1) { a = fe_sqr(a); b = fe_sqr(b); }
         if (KIND == 2) { a = fe_add(a, b); b = fe_add(b, a); }
         if (KIND == 3) { a = fe_sub(a, b); b = fe_sub(b, a); }
+        if (KIND == 4) { a = fe_inv(a); b = fe_inv(b); }
+        if (KIND == 5) { a = fe_inv_fermat(a); b = fe_inv_fermat(b); }
     }
     if (a.l[0] == 0x3fffffff && b.l[1] == 0x12345) out[0] = a.l[2];
 }
 
-// kind: 0 jac_madd, 1 jac_dbl, 2 jac_add
+// kind: 0 jac_madd, 1 jac_dbl, 2 jac_add, 3 xyzz_madd (the accumulation step of k_fixed_msm)
 template <class C, int KIND>
 __global__ void __launch_bounds__(128) k_group(uint32_t* out, uint32_t seed, int iters) {
     Aff<C> g = aff_generator<C>();
@@ -70,6 +73,17 @@ __global__ void __launch_bounds__(128) k_group(uint32_t* out, uint32_t seed, int
         if (KIND == 2) acc = jac_add(acc, q);
     }
     if (acc.X.l[0] == 0x3fffffff && acc.Y.l[1] == 0x12345) out[0] = acc.Z.l[2];
+}
+
+// the accumulation step of k_fixed_msm: XYZZ running sum += affine point
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_xyzz(uint32_t* out, uint32_t seed, int iters) {
+    Aff<C> g = aff_generator<C>();
+    uint32_t kw[1] = {seed + threadIdx.x + 2};
+    Aff<C> p = jac_to_aff(aff_mul_words(g, kw, 1));
+    Xyzz<C> xa = xyzz_madd(xyzz_dbl_aff(g), g);
+    for (int it = 0; it < iters; it++) xa = xyzz_madd(xa, p);
+    if (xa.X.l[0] == 0x3fffffff && xa.Y.l[1] == 0x12345) out[0] = xa.ZZ.l[2];
 }
 
 template <class F>
@@ -121,6 +135,10 @@ int main() {
     fld("fe_mul_blsfr", k_field<BlsFr, 0>, 2000, 256, 8);
     fld("fe_sqr_blsfr", k_field<BlsFr, 1>, 2000, 256, 8);
     fld("fe_mul_secpfp", k_field<SecpFp, 0>, 2000, 256, 8);
+    fld("fe_inv_blsfp", k_field<BlsFp, 4>, 40, 256, 8);
+    fld("fe_inv_fermat_blsfp", k_field<BlsFp, 5>, 4, 256, 8);
+    fld("fe_inv_blsfr", k_field<BlsFr, 4>, 40, 256, 8);
+    fld("fe_inv_secpfp", k_field<SecpFp, 4>, 40, 256, 8);
     auto grp = [&](const char* name, auto kern, int iters, int blocks_per_cu) {
         const int g = cus * blocks_per_cu;
         double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(g), dim3(128), 0, 0, o32, 5u, iters); }, 3);
@@ -130,6 +148,8 @@ int main() {
     grp("jac_madd_bls", k_group<Bls12381, 0>, 300, 8);
     grp("jac_dbl_bls", k_group<Bls12381, 1>, 300, 8);
     grp("jac_add_bls", k_group<Bls12381, 2>, 300, 8);
+    grp("xyzz_madd_bls", k_xyzz<Bls12381>, 300, 8);
+    grp("xyzz_madd_secp", k_xyzz<Secp256k1>, 300, 8);
     grp("jac_madd_secp", k_group<Secp256k1, 0>, 300, 8);
     grp("jac_dbl_secp", k_group<Secp256k1, 1>, 300, 8);
     printf(" \"end\": 0}\n");
