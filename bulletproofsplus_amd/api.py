@@ -354,7 +354,7 @@ class BatchVerifier:
                                           stream or None), "bpp_verifier_run")
 
 
-STAGES = ("from_wire", "verify_scalars", "fixed_msm", "var_msm", "finalize", "fixed_forward")
+STAGES = ("from_wire", "verify_scalars", "fixed_msm", "var_msm", "finalize")
 
 
 def _verifier_set_profiling(self, on: bool):
@@ -363,7 +363,7 @@ def _verifier_set_profiling(self, on: bool):
 
 def _verifier_profile(self):
     """-> ({stage: mean ms}, passes, blocks_per_proof of k_fixed_msm), HIP events on the launch stream"""
-    ms = (ctypes.c_float * len(STAGES))()
+    ms = (ctypes.c_float * 5)()
     passes = ctypes.c_size_t()
     bpp_ = ctypes.c_uint()
     check(_lib.lib().bpp_verifier_profile(self.handle, ms, ctypes.byref(passes), ctypes.byref(bpp_)),

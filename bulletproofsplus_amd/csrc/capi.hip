@@ -116,7 +116,7 @@ extern "C" size_t bpp_verifier_workspace_bytes(const bpp_verifier* v, size_t cou
     if (!v) return 0;
     size_t r = 0;
     dispatch(v->ctx.curve, [&](auto cv) -> int {
-        r = VerifyImpl<decltype(cv)>::ws_layout(v->s, count, v->batch_affine).total;
+        r = VerifyImpl<decltype(cv)>::ws_layout(v->s, count).total;
         return 0;
     });
     return r;

@@ -142,7 +142,8 @@ inline void store_generator(uint32_t* affm_words) {
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
-inline int make_shape(size_t n, size_t m, int c, VerifyShape& s) {
+// fr_modw: the scalar-field modulus as 8 little-endian 32-bit words, fr_bits its bit length.
+inline int make_shape(size_t n, size_t m, int c, const uint32_t* fr_modw, int fr_bits, VerifyShape& s) {
     const size_t mn = n * m;
     if (n == 0 || m == 0 || !is_pow2(mn)) return fail(BPP_E_ARG, "n*m must be a power of two");
     if (n > VS_MAXN || m > VS_MAXM) return fail(BPP_E_ARG, "n or m exceeds the supported maximum (64)");
@@ -158,13 +159,39 @@ inline int make_shape(size_t n, size_t m, int c, VerifyShape& s) {
     s.NF = (uint32_t)(2 * mn + 2);
     s.NV = (uint32_t)(3 + 2 * k + m);
     s.c = (uint32_t)c;
-    s.W = (258 + c - 1) / c;
+    // W - 1 signed windows below bit c (W-1) < fr_bits, then one unsigned top window for the rest of the value
+    s.W = (uint32_t)((fr_bits - 1) / c + 1);
     s.half = 1u << (c - 1);
     for (int t = 0; t < 10; t++) s.bias[t] = 0;
-    for (uint32_t j = 0; j < s.W; j++) {
+    for (uint32_t j = 0; j + 1 < s.W; j++) {
         const uint32_t bit = s.c * j + (s.c - 1);
         s.bias[bit >> 5] |= 1u << (bit & 31);
     }
+    // largest top digit: (r - 1 + bias) >> c (W - 1)
+    uint32_t v[10];
+    uint32_t carry = 0;
+    for (int t = 0; t < 10; t++) {
+        uint64_t x = (uint64_t)(t < 8 ? fr_modw[t] : 0u) + s.bias[t] + carry;
+        v[t] = (uint32_t)x;
+        carry = (uint32_t)(x >> 32);
+    }
+    uint32_t borrow = 1;   // - 1
+    for (int t = 0; t < 10 && borrow; t++) {
+        borrow = v[t] == 0 ? 1u : 0u;
+        v[t] -= 1u;
+    }
+    const uint32_t sh = s.c * (s.W - 1);
+    uint64_t top = 0;
+    for (int t = 9; t >= 0; t--) {
+        const int lo = 32 * t - (int)sh;   // bit position of word t after the shift
+        if (lo >= 32 && v[t]) return fail(BPP_E_ARG, "window_bits too small for this scalar field");
+        if (lo > -32 && lo < 32) top |= lo >= 0 ? (uint64_t)v[t] << lo : (uint64_t)(v[t] >> (-lo));
+    }
+    if (top == 0 || top >= ((uint64_t)1 << 31)) return fail(BPP_E_ARG, "window_bits too small for this scalar field");
+    s.top = (uint32_t)top;
+    const uint64_t per_f = (uint64_t)(s.W - 1) * s.half + s.top;
+    if (per_f >> 32) return fail(BPP_E_ARG, "window table too large");
+    s.per_f = (uint32_t)per_f;
     return BPP_OK;
 }
 

@@ -217,7 +217,7 @@ struct MsmImpl {
                                    const uint64_t* proof_points, size_t k, const uint64_t* proof_scalars,
                                    const uint64_t* V) {
         VerifyShape s;
-        int rc = make_shape(n, m, 8, s);
+        int rc = make_shape(n, m, 8, C::Fr::MODW, C::Fr::BITS, s);
         if (rc) return rc;
         if (k != s.k) return BPP_VERIFICATION_ERROR;  // wip.rs:335-337
         std::vector<uint64_t> pts((size_t)s.N * PW);

@@ -1,16 +1,14 @@
 // impl_verify.hpp -- the batch verifier (bpp_verifier_*): window tables in HBM + one pass of the hot path
 // over a device-resident batch.  One instantiation per curve (tu_verify_*.hip).
 #pragma once
-#include "batch_affine.hpp"
 #include "combined.hpp"
 #include "host_util.hpp"
 #include "pippenger.hpp"
 #include "prover_batch.hpp"
 
 // stages of one pass, in launch order (bpp_verifier_profile reports one duration per stage)
-// BPP_STAGE_FIXED_FWD is the forward pass of the batch-affine variant, a sub-interval of BPP_STAGE_FIXED_MSM
 enum { BPP_STAGE_FROM_WIRE = 0, BPP_STAGE_SCALARS, BPP_STAGE_FIXED_MSM, BPP_STAGE_VAR_MSM, BPP_STAGE_FINALIZE,
-       BPP_STAGE_FIXED_FWD, BPP_NUM_STAGES };
+       BPP_NUM_STAGES };
 constexpr int BPP_PROFILE_SLOTS = 64;  // passes remembered by the event ring
 
 struct bpp_verifier {
@@ -24,10 +22,6 @@ struct bpp_verifier {
     std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x BPP_NUM_STAGES x 2
     size_t passes_recorded = 0;
     unsigned last_blocks_per_proof = 0;
-    // fixed-generator MSM: pair the entries of neighbouring windows in affine coordinates first
-    // (batch_affine.hpp): 1 = whenever a thread's chain amortises its inversion, 0 = never (plain XYZZ kernel),
-    // 2 = always.  BPP_AMD_BATCH_AFFINE in the environment overrides the default at creation.
-    int batch_affine = 1;
     // the proof-point kernels run on a side stream, beside the fixed-generator MSM (their last stage, one
     // lane per proof, is latency bound and would otherwise leave the chip idle)
     hipStream_t side = nullptr;
@@ -51,15 +45,8 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
 }
 
 struct WsLayout {
-    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, ba_prefix, ba_inv, ba_sums, total;
+    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, total;
 };
-
-// batch-affine pairing pays once a thread's chain of pairs amortises its inversion (~40 M): at least two
-// generators per thread
-inline bool use_batch_affine(const VerifyShape& s, size_t count, int mode) {
-    if (mode == 0 || s.W < 2) return false;
-    return mode == 2 || cdiv(s.NF, blocks_per_proof(s, count) * FIXED_BLOCK) >= 2;
-}
 
 template <class C>
 struct VerifyImpl {
@@ -68,7 +55,7 @@ struct VerifyImpl {
     static constexpr int WW = 2 * N + 2;
     static constexpr int PW = WW / 2;
 
-    static WsLayout ws_layout(const VerifyShape& s, size_t count, int batch_affine) {
+    static WsLayout ws_layout(const VerifyShape& s, size_t count) {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         WsLayout w;
         size_t o = 0;
@@ -88,17 +75,6 @@ struct VerifyImpl {
         o += al(count * VAR_WINDOWS * JW * 4);                     // window sums
         w.vtbl = o;
         o += al(count * VAR_WINDOWS * 8 * JW * 4);                 // 8 lane-private buckets per (proof, window)
-        w.ba_prefix = w.ba_inv = w.ba_sums = o;
-        if (has_batch_affine<C>::value && use_batch_affine(s, count, batch_affine)) {
-            const unsigned per = blocks_per_proof(s, count);
-            const size_t nthreads = count * per * FIXED_BLOCK;
-            const size_t pairs = (size_t)cdiv(s.NF, per * FIXED_BLOCK) * ((s.W + 1) >> 1);   // longest chain of a thread
-            o += al(pairs * nthreads * N * 4);
-            w.ba_inv = o;
-            o += al(nthreads * N * 4);
-            w.ba_sums = o;
-            o += al(pairs * nthreads * 2 * N * 4);
-        }
         w.total = o;
         return w;
     }
@@ -106,7 +82,7 @@ struct VerifyImpl {
     static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
                       int window_bits, bpp_verifier** out) {
         VerifyShape s;
-        int rc = make_shape(n, m, window_bits, s);
+        int rc = make_shape(n, m, window_bits, C::Fr::MODW, C::Fr::BITS, s);
         if (rc) return rc;
         std::vector<uint64_t> fixed((size_t)s.NF * PW);
         std::memcpy(fixed.data(), gh, 2 * PW * 8);
@@ -123,8 +99,7 @@ struct VerifyImpl {
         bpp_verifier* v = new bpp_verifier();
         v->ctx = ctx;
         v->s = s;
-        if (const char* e = std::getenv("BPP_AMD_BATCH_AFFINE")) v->batch_affine = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
-        const size_t entries = (size_t)s.NF * s.W * s.half;
+        const size_t entries = (size_t)s.NF * s.per_f;
         v->table_bytes = entries * 2 * N * 4;
         hipError_t e = v->table.alloc(v->table_bytes);
         if (e != hipSuccess) {
@@ -133,7 +108,7 @@ struct VerifyImpl {
         }
         hipLaunchKernelGGL(k_tbl_bases<C>, dim3(cdiv(s.NF, 64)), dim3(64), 0, nullptr, s, dfixed.u32(), v->table.u32());
         // fill in slabs of generators so that one launch stays well below 2^31 blocks
-        const size_t per_f = (size_t)s.W * s.half;
+        const size_t per_f = s.per_f;
         const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 28) / per_f);
         for (uint32_t f0 = 0; f0 < s.NF; f0 += slab) {
             const uint32_t f1 = std::min<uint32_t>(s.NF, f0 + slab);
@@ -165,7 +140,7 @@ struct VerifyImpl {
                    const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
                    uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st) {
         const VerifyShape& s = v->s;
-        const WsLayout L = ws_layout(s, count, v->batch_affine);
+        const WsLayout L = ws_layout(s, count);
         if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
         uint8_t* ws = static_cast<uint8_t*>(d_workspace);
         uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
@@ -211,28 +186,8 @@ struct VerifyImpl {
         HIPCHK(hipEventRecord(v->ev_join, sd));
         // fixed-generator part on the caller's stream
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-        HIPCHK(mark(2 * BPP_STAGE_FIXED_FWD, st));
-        bool ba_done = false;
-        if constexpr (has_batch_affine<C>::value) {
-            if (use_batch_affine(s, count, v->batch_affine)) {
-                uint32_t* w_pre = reinterpret_cast<uint32_t*>(ws + L.ba_prefix);
-                uint32_t* w_inv = reinterpret_cast<uint32_t*>(ws + L.ba_inv);
-                hipLaunchKernelGGL(k_ba_forward<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), 0, st, s, w_sc,
-                                   v->table.u32(), w_pre, w_inv, bpp_);
-                HIPCHK(mark(2 * BPP_STAGE_FIXED_FWD + 1, st));
-                uint32_t* w_sum = reinterpret_cast<uint32_t*>(ws + L.ba_sums);
-                hipLaunchKernelGGL(k_ba_backward<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), 0, st, s, w_sc,
-                                   v->table.u32(), w_pre, w_inv, w_sum, bpp_);
-                hipLaunchKernelGGL(k_ba_accumulate<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK),
-                                   FIXED_BLOCK * JW * 4, st, s, w_sum, w_fp, bpp_);
-                ba_done = true;
-            }
-        }
-        if (!ba_done) {
-            HIPCHK(mark(2 * BPP_STAGE_FIXED_FWD + 1, st));
-            hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4,
-                               st, s, w_sc, v->table.u32(), w_fp, bpp_);
-        }
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
+                           s, w_sc, v->table.u32(), w_fp, bpp_);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         // join
         HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));

@@ -5,8 +5,10 @@
 //   "affm" points    : Montgomery x | y                 (2N words)     -- pk, proof points, tables
 //   jacobian partials: Montgomery X | Y | Z             (3N words)
 //   scalars          : canonical, 8 words (4 x u64)
-//   window table     : entry[(f * W + j) * half + (d - 1)] = d * 2^(c j) * F_f   (affm), d = 1..half,
-//                      half = 2^(c-1); F = [g, h, G_0.., H_0..] the verifier's fixed generators.
+//   window table     : entry[f * per_f + j * half + (d - 1)] = d * 2^(c j) * F_f   (affm); windows 0..W-2 hold
+//                      d = 1..half (signed digits, half = 2^(c-1)), the top window W-1 holds d = 1..top (its digit
+//                      is the unsigned remainder of the scalar, so no window is spent on a recoding carry);
+//                      per_f = (W-1) half + top; F = [g, h, G_0.., H_0..] the verifier's fixed generators.
 //
 // Kernel inventory (each names the reference call site it serves; paths relative to /root/reference/src):
 //   k_points_from_wire   wire -> affm (+ on-curve check)
@@ -213,7 +215,9 @@ struct VerifyShape {
     uint32_t N;                // MulVec length 2mn + 2k + m + 5
     uint32_t NF, NV;           // fixed terms 2mn + 2, proof-dependent terms 3 + 2k + m
     uint32_t c, W, half;       // window bits, windows, 2^(c-1)
-    uint32_t bias[10];         // sum_j half * 2^(c j) as 32-bit words (signed-digit recoding bias)
+    uint32_t top;              // entries of the top window (its digit is unsigned: 0..top)
+    uint32_t per_f;            // table entries per generator: (W-1) * half + top
+    uint32_t bias[10];         // sum_{j < W-1} half * 2^(c j) as 32-bit words (signed-digit recoding bias)
 };
 
 // index of fixed generator f (0 = g, 1 = h, 2.. = G_i, 2+mn.. = H_i) in the MulVec
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t*
     if (f >= s.NF) return;
     Aff<C> p = aff_ldg<C>(fixed_pts + (size_t)f * 2 * N);
     for (uint32_t j = 0; j < s.W; j++) {
-        aff_stg<C>(table + ((size_t)(f * s.W + j) * s.half) * 2 * N, p);
+        aff_stg<C>(table + ((size_t)f * s.per_f + (size_t)j * s.half) * 2 * N, p);
         if (j + 1 < s.W) {
             Jac<C> q = jac_from_aff(p);
             for (uint32_t t = 0; t < s.c; t++) q = jac_dbl(q);
@@ -570,12 +574,14 @@ template <class C>
 __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t f_begin, uint32_t f_end) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
-    const size_t per_f = (size_t)s.W * s.half;
+    const size_t per_f = s.per_f;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)(f_end - f_begin) * per_f;
     if (idx >= total) return;
     const size_t e = (size_t)f_begin * per_f + idx;
-    const uint32_t d = (uint32_t)(e % s.half) + 1;
+    const uint32_t in_f = (uint32_t)(idx % per_f);
+    const uint32_t j = min(in_f / s.half, s.W - 1);   // the top window may hold more than `half` entries
+    const uint32_t d = in_f - j * s.half + 1;
     if (d == 1) return;
     const size_t base_e = e - (d - 1);
     Aff<C> base = aff_ldg<C>(table + base_e * 2 * N);
@@ -587,8 +593,8 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // ---- the verification MulVec ---------------------------------------------------------------------------
 
 // Fixed-generator part: for proof b = blockIdx.y, sum_f scalar_f * F_f through the window tables.
-// scalar + bias -> W unsigned windows -> signed digits in [-half, half) -> one table gather and one mixed
-// addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
+// scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
+// one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
 // that.  partials: [count][per] jacobians.
 // ROLE only separates the launches in profiles: 0 = the batch verifier's hot path, 1 = prover / combined check.
 template <class C, int ROLE = 0>
@@ -629,7 +635,8 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
                 }
                 j = 0;
             }
-            const int32_t dg = (int32_t)(w[0] & mask) - (int32_t)s.half;
+            // windows below the top: signed digit; top window: what is left of the value, unsigned (<= top)
+            const int32_t dg = j + 1 < s.W ? (int32_t)(w[0] & mask) - (int32_t)s.half : (int32_t)w[0];
 #pragma unroll
             for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
             w[9] >>= s.c;
@@ -638,7 +645,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
             if (j == s.W) f += stride;
             if (dg != 0) {
                 const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
-                ld_words<2 * N>(table + (((size_t)ff * s.W + jj) * s.half + (mag - 1)) * 2 * N, raw);
+                ld_words<2 * N>(table + ((size_t)ff * s.per_f + (size_t)jj * s.half + (mag - 1)) * 2 * N, raw);
                 nneg = dg < 0;
                 have = true;
                 return;

@@ -165,10 +165,9 @@ int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n,
 
 /* Per-stage timing with HIP events recorded on the caller's stream around each kernel of a pass
  * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant], 3 proof-point MSM,
- * 4 finalize, 5 the forward (denominator-product) kernel of the fixed-generator MSM, a sub-interval of stage 2
- * and zero when the batch-affine pairing is not in use).  Stage 3 runs on the verifier's side stream
- * CONCURRENTLY with stage 2, so the stage times do not add up to the step time.  bpp_verifier_profile averages
- * over the passes recorded since profiling was switched on (at most 64): out_stage_ms[6]. */
+ * 4 finalize).  Stage 3 runs on the verifier's side stream CONCURRENTLY with stage 2, so the stage times do
+ * not add up to the step time.  bpp_verifier_profile averages over the passes recorded since profiling was
+ * switched on (at most 64): out_stage_ms[5]. */
 int bpp_verifier_set_profiling(bpp_verifier *v, int on);
 int bpp_verifier_profile(bpp_verifier *v, float *out_stage_ms, size_t *out_passes, unsigned *out_blocks_per_proof);
 

@@ -23,11 +23,3 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
-
-
-@pytest.fixture(params=["plain", "batch_affine"])
-def fixed_msm_mode(request, monkeypatch):
-    """Both variants of the fixed-generator MSM: the plain XYZZ kernel and the batch-affine pairing
-    (csrc/batch_affine.hpp), forced regardless of batch size.  Read by bpp_verifier_create."""
-    monkeypatch.setenv("BPP_AMD_BATCH_AFFINE", "0" if request.param == "plain" else "2")
-    return request.param

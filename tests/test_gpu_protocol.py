@@ -86,7 +86,7 @@ def test_prove_and_verify_reference_sizes(golden):
     ("secp256k1", 8, [77], [9], 3),
     ("bls12_381", 4, [9, 3, 15, 0], [1, 2, 3, 4], 6),
 ])
-def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c, fixed_msm_mode):
+def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
     """Batch of valid / tampered / out-of-range proofs: scalars, result point and verdict == oracle."""
     torch = need_gpu()
     import bulletproofsplus_amd as B
@@ -136,7 +136,7 @@ def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c, fixed_msm_mode)
 
 
 @pytest.mark.parametrize("case_idx,c", [(2, 13), (2, 8), (0, 10), (1, 11)])
-def test_batch_verifier_reference_sizes(golden, case_idx, c, fixed_msm_mode):
+def test_batch_verifier_reference_sizes(golden, case_idx, c):
     """(64,16) [C2/C4], main.rs (64,2), C1 (32,1): table path == oracle scalars, identity result, verdicts."""
     torch = need_gpu()
     import bulletproofsplus_amd as B
@@ -178,7 +178,7 @@ def test_batch_verifier_reference_sizes(golden, case_idx, c, fixed_msm_mode):
     assert ok2.tolist() == [0, 1, 1, 0] and np.array_equal(sc2, got_sc)
 
 
-def test_window_sizes_agree(golden, fixed_msm_mode):
+def test_window_sizes_agree(golden):
     """size-independent property: every window width gives the same MulVec result for the same proof."""
     torch = need_gpu()
     import bulletproofsplus_amd as B
@@ -393,7 +393,7 @@ def test_full_size_batch_round_trip_properties():
 
 @pytest.mark.parametrize("cname,n,vals,gams", [("bls12_381", 8, [200, 5], [3, 7]), ("secp256k1", 8, [77], [9]),
                                                ("ed25519", 4, [9, 3, 15, 0], [1, 2, 3, 4])])
-def test_arbitrary_per_proof_challenges(cname, n, vals, gams, monkeypatch, fixed_msm_mode):
+def test_arbitrary_per_proof_challenges(cname, n, vals, gams, monkeypatch):
     """The verifier is not tied to the reference's constant "transcript": with full-width per-proof
     challenges (y, z, e, one e_t per round) supplied through d_challenges, the MulVec scalars, result and
     verdict equal the big-integer restatement run with the same challenges.  (The reference itself has no
@@ -443,7 +443,7 @@ def test_arbitrary_per_proof_challenges(cname, n, vals, gams, monkeypatch, fixed
     assert ok3.tolist() == [1, 0, 1]
 
 
-def test_secp256k1_reference_size_against_oracle(fixed_msm_mode):
+def test_secp256k1_reference_size_against_oracle():
     """secp256k1 at n = 64, m = 4 (mn = 256): batched prover == C oracle prover, verifier scalars == oracle."""
     torch = need_gpu()
     import bulletproofsplus_amd as B
@@ -462,7 +462,7 @@ def test_secp256k1_reference_size_against_oracle(fixed_msm_mode):
     assert ok.tolist() == [0] and np.array_equal(got_sc[0], exp_sc) and a.is_zero(got_res[0])
 
 
-def test_maximum_supported_shape_round_trip(fixed_msm_mode):
+def test_maximum_supported_shape_round_trip():
     """n = 64, m = 64 (mn = 4096, k = 12, 8 285 MulVec terms, 91 proof points): the largest shape the engine
     accepts.  Exercises the > 64 KB dynamic-LDS path of k_verify_scalars and NV > 64 in the proof-point
     kernels.  Round trip + tamper + combined check; shapes beyond the limit are usage errors."""

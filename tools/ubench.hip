@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) k_inst(uint64_t* out, uint32_t seed) {
 // kind: 0 fe_mul, 1 fe_sqr, 2 fe_add, 3 fe_sub, 4 fe_inv (safegcd), 5 fe_inv_fermat
 template <class P, int KIND>
 __global__ void __launch_bounds__(256) k_field(uint32_t* out, uint32_t seed, int iters) {
-    Fe<P> a = fe_from_u32<P>(seed + threadIdx.x + 1), b = fe_from_u32<P>(seed * 7 + blockIdx.x + 3);
+    Fe<P> a = fe_from_u32<P>(seed + threadIdx.x + 1), b = fe_from_u32<P>(seed * 7 + blockIdx.x + 3 * threadIdx.x + 3);   // both per-lane: a wave-uniform operand would be computed on the scalar unit
     for (int it = 0; it < iters; it++) {
         if (KIND == 0) { a = fe_mul(a, b); b = fe_mul(b, a); }
         if (KIND == 1) { a = fe_sqr(a); b = fe_sqr(b); }
