@@ -225,6 +225,16 @@ BPP_HD Aff<C> jac_to_aff(const Jac<C>& p) {
     return r;
 }
 
+// affine image of (X, Y, Z) given zi = Z^-1 (shared-inversion normalisation of several points)
+template <class C>
+BPP_HD Aff<C> jac_scale_to_aff(const Jac<C>& p, const Fe<typename C::Fp>& zi) {
+    const Fe<typename C::Fp> zi2 = fe_sqr(zi);
+    Aff<C> r;
+    r.x = fe_mul(p.X, zi2);
+    r.y = fe_mul(p.Y, fe_mul(zi2, zi));
+    return r;
+}
+
 // ---- XYZZ accumulator (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; ZZ = 0 encodes infinity) ----------------------
 // Used where a running sum only ever receives affine points (the fixed-generator MSM): the mixed addition
 // costs 8M + 2S (madd-2008-s) against 7M + 4S for jacobian madd-2007-bl, with about half the add/sub work.

@@ -162,6 +162,12 @@ BPP_HD Aff<Ed25519> jac_to_aff(const Jac<Ed25519>& p) {
     r.y = fe_mul(p.Y, zi);
     return r;
 }
+BPP_HD Aff<Ed25519> jac_scale_to_aff(const Jac<Ed25519>& p, const ed::F& zi) {
+    Aff<Ed25519> r;
+    r.x = fe_mul(p.X, zi);
+    r.y = fe_mul(p.Y, zi);
+    return r;
+}
 BPP_HD bool jac_eq(const Jac<Ed25519>& p, const Jac<Ed25519>& q) {
     return fe_mul(p.X, q.Z) == fe_mul(q.X, p.Z) && fe_mul(p.Y, q.Z) == fe_mul(q.Y, p.Z);
 }

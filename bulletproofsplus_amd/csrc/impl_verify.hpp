@@ -45,7 +45,7 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
 }
 
 struct WsLayout {
-    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, total;
+    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, vscr, total;
 };
 
 template <class C>
@@ -74,7 +74,9 @@ struct VerifyImpl {
         w.vwsum = o;
         o += al(count * VAR_WINDOWS * JW * 4);                     // window sums
         w.vtbl = o;
-        o += al(count * VAR_WINDOWS * 8 * JW * 4);                 // 8 lane-private buckets per (proof, window)
+        o += al(count * s.NV * VAR_MULTIPLES * 2 * N * 4);         // 1P..8P of every proof point, affine
+        w.vscr = o;
+        o += al(count * s.NV * 2 * (VAR_MULTIPLES - 1) * N * 4);   // Z's and their prefix products while normalising
         w.total = o;
         return w;
     }
@@ -179,8 +181,10 @@ struct VerifyImpl {
         const size_t vlanes = count * VAR_WINDOWS;
         HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, sd));
         hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, sd, s, w_sc, w_vd, npts);
-        hipLaunchKernelGGL(k_var_buckets<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, s, w_vd, w_pts, w_vt,
-                           w_vw, vlanes);
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, w_pts, w_vt,
+                           reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
+        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, s, w_vd, w_vt, w_vw,
+                           vlanes);
         hipLaunchKernelGGL(k_var_horner<C>, dim3(cdiv(count, 64)), dim3(64), 0, sd, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, sd));
         HIPCHK(hipEventRecord(v->ev_join, sd));

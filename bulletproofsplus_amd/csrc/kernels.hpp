@@ -19,7 +19,7 @@
 //                                                               wip.rs:254-295
 //   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums)
 //                                                               range/mod.rs:480-503 / wip.rs:297-320
-//   k_var_digits/buckets/horner  the 3+2k+m proof-dependent terms of the same MulVec (bucket method per proof)
+//   k_var_digits/tables/windows/horner  the 3+2k+m proof-dependent terms of the same MulVec (Straus per proof)
 //   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327
 //   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new)
 #pragma once
@@ -664,13 +664,16 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
 }
 
 // ---- proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments ---------------
-// A bucket method PER PROOF so that the ~260 doublings are paid once per proof, not once per point:
+// Straus per proof, with the ~260 doublings paid once per proof and every addition a MIXED one:
 //   k_var_digits   one lane per (proof, point): 65 signed 4-bit digits of (scalar + 0x88..8), one byte each
-//   k_var_buckets  one lane per (proof, window): the proof's NV points go into 8 lane-private buckets
-//                  (jacobian, HBM scratch that stays in L2 / Infinity Cache), then sum_k k * B_k
+//   k_var_tables   one lane per (proof, point): the multiples 1P..8P as AFFINE points -- a chain of mixed
+//                  additions, then one inversion (safegcd) of the product of the seven Z's
+//   k_var_windows  one lane per (proof, window): sum over the proof's points of +-T[point][|digit|] in an XYZZ
+//                  accumulator (8M + 2S each, no bucket reduction)
 //   k_var_horner   one lane per proof: Horner over the 65 window sums (4 doublings per step)
 constexpr uint32_t VAR_WINDOWS = 65;   // 4-bit windows of a 260-bit value
 constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple)
+constexpr uint32_t VAR_MULTIPLES = 8;  // table entries per proof point: 1P .. 8P
 
 template <class C>
 __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_t* __restrict__ scalars,
@@ -703,11 +706,69 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
     st_words<VAR_DIGIT_STRIDE / 4>(dst, out);
 }
 
-// lane = (proof b, window j).  bucket scratch: [lane][8] jacobians.  wsum: [proof][VAR_WINDOWS] jacobians.
+// lane = (proof, point).  tables: [lane][8] affm.  scratch: [lane][14] field elements (Z_k and their prefix
+// products, k = 2..8).
 template <class C>
-__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_buckets(VerifyShape s, const uint8_t* __restrict__ digits,
-                                                                         const uint32_t* __restrict__ proof_pts,
-                                                                         uint32_t* __restrict__ bucket_scratch,
+__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_tables(const uint32_t* __restrict__ proof_pts,
+                                                                        uint32_t* __restrict__ tables,
+                                                                        uint32_t* __restrict__ scratch, size_t lanes) {
+    using P = typename C::Fp;
+    using F = Fe<P>;
+    constexpr int N = P::N;
+    constexpr int M = (int)VAR_MULTIPLES;
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes) return;
+    uint32_t* T = tables + lane * M * 2 * N;
+    uint32_t* S = scratch + lane * 2 * (M - 1) * N;
+    const Aff<C> p = aff_ldg<C>(proof_pts + lane * 2 * N);
+    aff_stg<C>(T, p);
+    if (p.is_inf()) {   // an invalid point was replaced by infinity (k_points_from_wire): every multiple is infinity
+        for (int k = 1; k < M; k++) aff_stg<C>(T + (size_t)k * 2 * N, p);
+        return;
+    }
+    // k P in projective coordinates; X | Y parked in the table slot, Z and the running product of Z's in scratch
+    // A Weierstrass point outside the prime-order subgroup (BLS12-381 G1 has cofactor 3 * 11^2 * ...) can reach
+    // infinity inside the chain: such a multiple is parked as x = y = 0 with Z = 1, so the product of the Z's
+    // stays invertible and the scaled entry is the infinity encoding.  (Edwards: Z is never 0.)
+    Jac<C> J = aff_dbl(p);
+    F run = F::one();
+    uint32_t w[N];
+    for (int k = 1; k < M; k++) {
+        if (k > 1) J = jac_madd(J, p);
+        const bool at_inf = C::ID != 2 && J.is_inf();
+        const F z = at_inf ? F::one() : J.Z;
+        run = fe_mul(run, z);
+        fe_store(at_inf ? F::zero() : J.X, w);
+        st_words<N>(T + (size_t)k * 2 * N, w);
+        fe_store(at_inf ? F::zero() : J.Y, w);
+        st_words<N>(T + (size_t)k * 2 * N + N, w);
+        fe_store(z, w);
+        st_words<N>(S + (size_t)(k - 1) * N, w);
+        fe_store(run, w);
+        st_words<N>(S + (size_t)(M - 1 + k - 1) * N, w);
+    }
+    F inv = fe_inv(run);   // (Z_2 ... Z_8)^-1
+    for (int k = M - 1; k >= 1; k--) {
+        F zi = inv;
+        if (k > 1) {
+            ld_words<N>(S + (size_t)(M - 1 + k - 2) * N, w);   // prefix product up to k - 1
+            zi = fe_mul(inv, fe_load<P>(w));
+            ld_words<N>(S + (size_t)(k - 1) * N, w);
+            inv = fe_mul(inv, fe_load<P>(w));
+        }
+        Jac<C> q = J;   // only X and Y are read by jac_scale_to_aff
+        ld_words<N>(T + (size_t)k * 2 * N, w);
+        q.X = fe_load<P>(w);
+        ld_words<N>(T + (size_t)k * 2 * N + N, w);
+        q.Y = fe_load<P>(w);
+        aff_stg<C>(T + (size_t)k * 2 * N, jac_scale_to_aff(q, zi));
+    }
+}
+
+// lane = (proof b, window j): wsum[lane] = sum_v sign * T[b][v][|digit| - 1]
+template <class C>
+__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(VerifyShape s, const uint8_t* __restrict__ digits,
+                                                                         const uint32_t* __restrict__ tables,
                                                                          uint32_t* __restrict__ wsum, size_t lanes) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
@@ -715,27 +776,28 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_buckets(Verify
     if (lane >= lanes) return;
     const size_t b = lane / VAR_WINDOWS;
     const uint32_t j = (uint32_t)(lane % VAR_WINDOWS);
-    uint32_t* B = bucket_scratch + lane * 8 * JW;
-    uint32_t occupied = 0;   // bit k: bucket k (digit magnitude k+1) holds a point
+    const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + j;
+    const uint32_t* T = tables + b * s.NV * VAR_MULTIPLES * 2 * N;
+    Xyzz<C> acc = xyzz_inf<C>();
+    // one entry in flight: the gather of point v + 1 is issued before the addition of point v
+    uint32_t raw[2 * N];
+    int32_t d_next = (int32_t)dg[0] - 8;
+    if (d_next) ld_words<2 * N>(T + (size_t)((d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
     for (uint32_t v = 0; v < s.NV; v++) {
-        const int32_t dg = (int32_t)digits[(b * s.NV + v) * VAR_DIGIT_STRIDE + j] - 8;
-        if (dg == 0) continue;
-        const uint32_t kq = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
-        Aff<C> p = aff_ldg<C>(proof_pts + (b * s.NV + v) * 2 * N);
-        if (dg < 0) p = aff_neg(p);
-        Jac<C> acc;
-        if ((occupied >> kq) & 1u) acc = jac_madd(jac_ldg<C>(B + (size_t)kq * JW), p);
-        else acc = jac_from_aff(p);
-        occupied |= 1u << kq;
-        jac_stg<C>(B + (size_t)kq * JW, acc);
+        const int32_t d = d_next;
+        Aff<C> cur;
+        if (d) {
+            cur = aff_load<C>(raw);
+            if (d < 0) cur = aff_neg(cur);
+        }
+        if (v + 1 < s.NV) {
+            d_next = (int32_t)dg[(size_t)(v + 1) * VAR_DIGIT_STRIDE] - 8;
+            if (d_next)
+                ld_words<2 * N>(T + ((size_t)(v + 1) * VAR_MULTIPLES + (d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
+        }
+        if (d) acc = xyzz_madd(acc, cur);
     }
-    // sum_k (k+1) * B_k by descending running sums
-    Jac<C> run = jac_inf<C>(), tot = jac_inf<C>();
-    for (int kq = 7; kq >= 0; kq--) {
-        if ((occupied >> kq) & 1u) run = jac_add(run, jac_ldg<C>(B + (size_t)kq * JW));
-        tot = jac_add(tot, run);
-    }
-    jac_stg<C>(wsum + lane * JW, tot);
+    jac_stg<C>(wsum + lane * JW, xyzz_to_jac(acc));
 }
 
 // one lane per proof: out[b] = sum_j 16^j * wsum[b][j]

@@ -115,6 +115,12 @@ def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
     p2 = pts.copy(); p2[3] = pts[4] if pts.shape[0] > 4 else opk.gh[1]; add(p2, sc, V)  # L_0 replaced
     V2 = V.copy(); V2[-1] = O.point_neg(cid, V[-1]); add(pts, sc, V2)                  # commitment negated
     p2 = pts.copy(); p2[1] = O.point_to_wire(cid, None); add(p2, sc, V)                # wip.A = infinity
+    if cname == "bls12_381":
+        # (0, 2) lies on y^2 = x^3 + 4 but has order 3 (outside G1): its multiples reach infinity inside the
+        # proof-point tables (k_var_tables); the group law must still agree with the oracle's
+        p2 = pts.copy(); p2[2] = O.point_to_wire(cid, (0, 2)); add(p2, sc, V)
+        bls_p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+        p2 = pts.copy(); p2[0] = O.point_to_wire(cid, (0, bls_p - 2)); add(p2, sc, V)      # its negative, as A
     big = [v + (1 << n) if i == 0 else v for i, v in enumerate(vals)]                  # out of range
     bpts, bsc, bV = O.range_prove(opk, n, big, gams)
     add(bpts, bsc, bV)
