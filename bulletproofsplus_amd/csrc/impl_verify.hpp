@@ -22,15 +22,8 @@ struct bpp_verifier {
     std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x BPP_NUM_STAGES x 2
     size_t passes_recorded = 0;
     unsigned last_blocks_per_proof = 0;
-    // the proof-point kernels run on a side stream, beside the fixed-generator MSM (their last stage, one
-    // lane per proof, is latency bound and would otherwise leave the chip idle)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~bpp_verifier() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -127,13 +120,6 @@ struct VerifyImpl {
             delete v;
             return fail(BPP_E_HIP, std::string("table build failed: ") + hipGetErrorString(e));
         }
-        e = hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) {
-            delete v;
-            return fail(BPP_E_HIP, std::string("stream/event creation failed: ") + hipGetErrorString(e));
-        }
         *out = v;
         return BPP_OK;
     }
@@ -161,7 +147,6 @@ struct VerifyImpl {
         }
         auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
         v->last_blocks_per_proof = bpp_;
-        hipStream_t sd = v->side;
         HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
         HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
         hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
@@ -173,28 +158,23 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         HIPCHK(mark(2 * BPP_STAGE_SCALARS + 1, st));
-        // fork: proof-point part on the side stream
-        HIPCHK(hipEventRecord(v->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(sd, v->ev_fork, 0));
+        // proof-point MSM: digits, per-point tables, window sums (all arithmetic bound, so they simply run in
+        // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
         uint8_t* w_vd = ws + L.vdig;
         uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
         const size_t vlanes = count * VAR_WINDOWS;
-        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, sd));
-        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, sd, s, w_sc, w_vd, npts);
-        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, w_pts, w_vt,
+        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
+        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts);
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                            reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
-        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, sd, s, w_vd, w_vt, w_vw,
+        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                            vlanes);
-        hipLaunchKernelGGL(k_var_horner<C>, dim3(cdiv(count, 64)), dim3(64), 0, sd, w_vw, w_vp, count);
-        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, sd));
-        HIPCHK(hipEventRecord(v->ev_join, sd));
-        // fixed-generator part on the caller's stream
+        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
-                           s, w_sc, v->table.u32(), w_fp, bpp_);
+        const unsigned hb = cdiv(count, FIXED_BLOCK);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
+                           s, w_sc, v->table.u32(), w_fp, bpp_, hb, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
-        // join
-        HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
         hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
@@ -264,7 +244,8 @@ struct VerifyImpl {
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
         hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st, s,
-                           w_cs, v->table.u32(), w_fp, L.fixed_blocks);
+                           w_cs, v->table.u32(), w_fp, L.fixed_blocks, 0u, (const uint32_t*)nullptr,
+                           (uint32_t*)nullptr, (size_t)0);
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
         HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
@@ -318,7 +299,8 @@ struct VerifyImpl {
             hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
                                d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
             hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
-                               FIXED_BLOCK * JW * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per);
+                               FIXED_BLOCK * JW * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per, 0u,
+                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
             hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
                                d_pts.u32(), d_V.u32(), nv_total);
             HIPCHK(hipGetLastError());

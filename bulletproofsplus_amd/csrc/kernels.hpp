@@ -19,7 +19,7 @@
 //                                                               wip.rs:254-295
 //   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums)
 //                                                               range/mod.rs:480-503 / wip.rs:297-320
-//   k_var_digits/tables/windows/horner  the 3+2k+m proof-dependent terms of the same MulVec (Straus per proof)
+//   k_var_digits/tables/windows (+ Horner lanes inside k_fixed_msm)  the 3+2k+m proof-dependent terms of the same MulVec (Straus per proof)
 //   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327
 //   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new)
 #pragma once
@@ -36,6 +36,9 @@ constexpr unsigned VS_PB = 8;                 // proofs per block of k_verify_sc
 constexpr unsigned VS_BLOCK = VS_PB * 64;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
+constexpr uint32_t VAR_WINDOWS = 65;       // proof-point MSM: 4-bit windows of a 260-bit value
+constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple)
+constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P .. 8P
 // minimum waves per SIMD the register allocator must leave room for (512 VGPRs / waves)
 #ifndef BPP_FIXED_WAVES
 #define BPP_FIXED_WAVES 2
@@ -597,23 +600,55 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
 // that.  partials: [count][per] jacobians.
 // ROLE only separates the launches in profiles: 0 = the batch verifier's hot path, 1 = prover / combined check.
+// Last stage of the proof-point MSM (see k_var_tables / k_var_windows below), one lane per proof:
+// out[b] = sum_j 16^j * wsum[b][j] by Horner's rule -- 256 doublings that can only run one after the other.
+// Alone on the chip this is 128 waves of pure latency, so it does not get a launch of its own: the first
+// `horner_blocks` blocks of k_fixed_msm's grid run it, beside the blocks that do the fixed-generator sums.
+template <class C>
+__device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b) {
+    constexpr int JW = jac_words<C>();
+    const uint32_t* W = wsum + b * VAR_WINDOWS * JW;
+    Jac<C> acc = jac_ldg<C>(W + (size_t)(VAR_WINDOWS - 1) * JW);
+    for (int j = (int)VAR_WINDOWS - 2; j >= 0; j--) {
+        if (!acc.is_inf()) {
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+            acc = jac_dbl(acc);
+        }
+        acc = jac_add(acc, jac_ldg<C>(W + (size_t)j * JW));
+    }
+    jac_stg<C>(out + b * JW, acc);
+}
+
 template <class C, int ROLE = 0>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
-                            const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per) {
+                            const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per,
+                            uint32_t horner_blocks, const uint32_t* __restrict__ wsum, uint32_t* __restrict__ var_out,
+                            size_t horner_count) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     extern __shared__ __align__(16) uint32_t lds[];
-    // flat grid: block = proof * per + part   (`per` blocks share one proof's generators)
-    const size_t b = blockIdx.x / per;
-    const uint32_t part = blockIdx.x % per;
+    if (blockIdx.x < horner_blocks) {   // block-uniform: the Horner lanes of the proof-point MSM
+        const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (lane < horner_count) var_horner_lane<C>(wsum, var_out, lane);
+        return;
+    }
+    // flat grid after the Horner blocks: block = proof * per + part   (`per` blocks share one proof's generators)
+    const uint32_t bid = blockIdx.x - horner_blocks;
+    const size_t b = bid / per;
+    const uint32_t part = bid % per;
     const uint32_t* sc = scalars + b * (size_t)s.N * 8;
     const uint32_t mask = (1u << s.c) - 1u;
     const uint32_t stride = per * blockDim.x;
     Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
-    // software pipeline: the table entry of step t+1 is gathered while the mixed addition of step t runs
+    // software pipeline: the table entry of step t+1 is gathered while the mixed addition of step t runs, and
+    // the scalar of the NEXT generator is loaded while the windows of the current one are consumed (a load
+    // issued at the point of use would expose its full latency once per generator, i.e. every W additions)
     uint32_t f = part * blockDim.x + threadIdx.x;
-    uint32_t j = s.W;  // forces the first scalar load
-    uint32_t w[10];
+    uint32_t j = s.W;  // forces the first scalar to be taken from `wn`
+    uint32_t w[10], wn[8];
+    if (f < s.NF) ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, wn);
     bool have = false;   // a prefetched entry is pending
     bool nneg = false;   // ... and must be negated when consumed
     uint32_t raw[2 * N]; // its packed words, untouched until consumption so the gather stays in flight
@@ -622,17 +657,15 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
         while (true) {
             if (j == s.W) {
                 if (f >= s.NF) return;
-                ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, w);
-                w[8] = 0;
-                w[9] = 0;
-                // + bias K = sum_j half * 2^(c j): window j of (scalar + K) minus half is the signed digit
+                // + bias K = sum_{j < W-1} half * 2^(c j): window j of (scalar + K) minus half is the signed digit
                 uint32_t carry = 0;
 #pragma unroll
                 for (int t = 0; t < 10; t++) {
-                    uint64_t x = (uint64_t)w[t] + s.bias[t] + carry;
+                    uint64_t x = (uint64_t)(t < 8 ? wn[t] : 0u) + s.bias[t] + carry;
                     w[t] = (uint32_t)x;
                     carry = (uint32_t)(x >> 32);
                 }
+                if (f + stride < s.NF) ld_words<8>(sc + (size_t)fixed_term_index(s, f + stride) * 8, wn);
                 j = 0;
             }
             // windows below the top: signed digit; top window: what is left of the value, unsigned (<= top)
@@ -660,7 +693,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
         acc = xyzz_madd(acc, cur);
     }
     Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)blockIdx.x * JW, sum);
+    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)bid * JW, sum);
 }
 
 // ---- proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments ---------------
@@ -670,10 +703,8 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
 //                  additions, then one inversion (safegcd) of the product of the seven Z's
 //   k_var_windows  one lane per (proof, window): sum over the proof's points of +-T[point][|digit|] in an XYZZ
 //                  accumulator (8M + 2S each, no bucket reduction)
-//   k_var_horner   one lane per proof: Horner over the 65 window sums (4 doublings per step)
-constexpr uint32_t VAR_WINDOWS = 65;   // 4-bit windows of a 260-bit value
-constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple)
-constexpr uint32_t VAR_MULTIPLES = 8;  // table entries per proof point: 1P .. 8P
+//   var_horner_lane  one lane per proof: Horner over the 65 window sums (4 doublings per step), run by the
+//                  leading blocks of k_fixed_msm's grid
 
 template <class C>
 __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_t* __restrict__ scalars,
@@ -798,27 +829,6 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
         if (d) acc = xyzz_madd(acc, cur);
     }
     jac_stg<C>(wsum + lane * JW, xyzz_to_jac(acc));
-}
-
-// one lane per proof: out[b] = sum_j 16^j * wsum[b][j]
-template <class C>
-__global__ void __launch_bounds__(64) k_var_horner(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out,
-                                                   size_t count) {
-    constexpr int JW = jac_words<C>();
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= count) return;
-    const uint32_t* W = wsum + b * VAR_WINDOWS * JW;
-    Jac<C> acc = jac_ldg<C>(W + (size_t)(VAR_WINDOWS - 1) * JW);
-    for (int j = (int)VAR_WINDOWS - 2; j >= 0; j--) {
-        if (!acc.is_inf()) {
-            acc = jac_dbl(acc);
-            acc = jac_dbl(acc);
-            acc = jac_dbl(acc);
-            acc = jac_dbl(acc);
-        }
-        acc = jac_add(acc, jac_ldg<C>(W + (size_t)j * JW));
-    }
-    jac_stg<C>(out + b * JW, acc);
 }
 
 // expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError

@@ -163,11 +163,11 @@ int bpp_verifier_run_combined(bpp_verifier *v, const uint64_t *d_points, const u
                               void *d_workspace, size_t workspace_bytes, void *stream);
 int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n, uint32_t *d_ok, void *stream);
 
-/* Per-stage timing with HIP events recorded on the caller's stream around each kernel of a pass
- * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant], 3 proof-point MSM,
- * 4 finalize).  Stage 3 runs on the verifier's side stream CONCURRENTLY with stage 2, so the stage times do
- * not add up to the step time.  bpp_verifier_profile averages over the passes recorded since profiling was
- * switched on (at most 64): out_stage_ms[5]. */
+/* Per-stage timing with HIP events recorded on the caller's stream around the kernels of a pass
+ * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant; its first blocks also run
+ * the Horner stage of the proof-point MSM], 3 proof-point MSM: digits, per-point tables, window sums,
+ * 4 finalize).  The stages run back to back on one stream.  bpp_verifier_profile averages over the passes
+ * recorded since profiling was switched on (at most 64): out_stage_ms[5]. */
 int bpp_verifier_set_profiling(bpp_verifier *v, int on);
 int bpp_verifier_profile(bpp_verifier *v, float *out_stage_ms, size_t *out_passes, unsigned *out_blocks_per_proof);
 
