@@ -37,8 +37,10 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
     return std::max(1u, std::min(b, cdiv(s.NF, FIXED_BLOCK)));
 }
 
+constexpr unsigned FOLD_GROUP = 8;   // thread partials summed by one lane of k_partials_fold
+
 struct WsLayout {
-    size_t pts, bad, scalars, fpart, vpart, vdig, vwsum, vtbl, vscr, total;
+    size_t pts, bad, scalars, fthread, fpart, vpart, vdig, vwsum, vtbl, vscr, total;
 };
 
 template <class C>
@@ -58,8 +60,10 @@ struct VerifyImpl {
         o += al(count * 4);
         w.scalars = o;
         o += al(count * (size_t)s.N * 32);
+        w.fthread = o;
+        o += al(count * blocks_per_proof(s, count) * FIXED_BLOCK * JW * 4);                // one partial per thread
         w.fpart = o;
-        o += al(count * blocks_per_proof(s, count) * JW * 4);
+        o += al(count * blocks_per_proof(s, count) * (FIXED_BLOCK / FOLD_GROUP) * JW * 4);  // folded 8 to 1
         w.vpart = o;
         o += al(count * JW * 4);                                   // one jacobian per proof
         w.vdig = o;
@@ -172,11 +176,15 @@ struct VerifyImpl {
         HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
         const unsigned hb = cdiv(count, FIXED_BLOCK);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st,
-                           s, w_sc, v->table.u32(), w_fp, bpp_, hb, w_vw, w_vp, count);
+        uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), 0, st, s, w_sc,
+                           v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, bpp_, w_vp, 1u,
+        const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);   // partials per proof after the fold
+        hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
+                           count * folded);
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, folded, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());

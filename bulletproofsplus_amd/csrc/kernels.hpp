@@ -598,7 +598,8 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 // Fixed-generator part: for proof b = blockIdx.y, sum_f scalar_f * F_f through the window tables.
 // scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
 // one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
-// that.  partials: [count][per] jacobians.
+// that.  partials: ROLE 0: [count][per][blockDim.x] jacobians (one per thread, summed by k_partials_fold);
+// ROLE 1: [count][per] (block sums).
 // ROLE only separates the launches in profiles: 0 = the batch verifier's hot path, 1 = prover / combined check.
 // Last stage of the proof-point MSM (see k_var_tables / k_var_windows below), one lane per proof:
 // out[b] = sum_j 16^j * wsum[b][j] by Horner's rule -- 256 doublings that can only run one after the other.
@@ -692,8 +693,27 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
         fetch();
         acc = xyzz_madd(acc, cur);
     }
-    Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
-    if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)bid * JW, sum);
+    if (ROLE == 0) {
+        // one partial per THREAD: a tree reduction here would run 7 jacobian additions with most lanes idle
+        // (~4.5 % of the block's time); k_partials_fold sums them with every lane busy
+        jac_stg<C>(partials + ((size_t)bid * blockDim.x + threadIdx.x) * JW, xyzz_to_jac(acc));
+    } else {
+        Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
+        if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)bid * JW, sum);
+    }
+}
+
+// out[i] = sum of in[i * group .. i * group + group - 1]   (jacobian partials, one lane per output)
+template <class C>
+__global__ void __launch_bounds__(64) k_partials_fold(const uint32_t* __restrict__ in, uint32_t group,
+                                                      uint32_t* __restrict__ out, size_t n_out) {
+    constexpr int JW = jac_words<C>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const uint32_t* src = in + i * group * JW;
+    Jac<C> acc = jac_ldg<C>(src);
+    for (uint32_t t = 1; t < group; t++) acc = jac_add(acc, jac_ldg<C>(src + (size_t)t * JW));
+    jac_stg<C>(out + i * JW, acc);
 }
 
 // ---- proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments ---------------
