@@ -237,6 +237,18 @@ def main():
         dom_ms = stage_ms["fixed_msm"]
         alg_bytes = Bsz * NF * term_bytes                   # algorithmic bytes of one k_fixed_msm launch
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # the ALU-side view of the same kernel: mixed additions per second against the rate of a register-resident
+        # loop of the same addition (tools/ubench.hip on this GPU model, profiles/ubench_r01_final.json)
+        fr_bits = {"bls12_381": 255, "secp256k1": 256, "ed25519": 253}[args.curve]
+        windows = (fr_bits - 1) // args.window + 1
+        adds = Bsz * NF * windows
+        add_rate = adds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        add_peak = None
+        try:
+            uj = json.load(open(os.path.join(ROOT, "profiles", "ubench_r01_final.json")))
+            add_peak = uj[{"bls12_381": "xyzz_madd_bls", "secp256k1": "xyzz_madd_secp"}[args.curve]]["Gops"]
+        except Exception:
+            add_peak = None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_fixed_msm.json")
         if os.path.exists(pmc):
@@ -259,7 +271,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms, "launches_timed": passes,
                          "blocks_per_proof": bpp_,
-                         "note": "integer-ALU bound, not HBM bound: see DESIGN.md (ALU roofline in profiles/)"},
+                         "alu": {"unit": "G mixed additions/s", "achieved": add_rate, "peak": add_peak,
+                                 "frac": (add_rate / add_peak) if add_peak else None,
+                                 "additions_per_launch": adds,
+                                 "peak_source": "register-resident XYZZ mixed-addition loop, tools/ubench.hip (profiles/ubench_r01_final.json)"},
+                         "note": "integer-ALU bound, not HBM bound (DESIGN.md section 4): `alu` is the meaningful ceiling"},
             "stage_ms": stage_ms,
             "combined_check": comb,
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},

@@ -37,6 +37,12 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
     return std::max(1u, std::min(b, cdiv(s.NF, FIXED_BLOCK)));
 }
 
+// dynamic LDS of a k_fixed_msm launch: the gather ring, reused by the block reduction of ROLE 1
+template <class C>
+constexpr unsigned fixed_lds() {
+    return std::max<unsigned>(fixed_lds_bytes<C>(), FIXED_BLOCK * jac_words<C>() * 4);
+}
+
 constexpr unsigned FOLD_GROUP = 8;   // thread partials summed by one lane of k_partials_fold
 
 struct WsLayout {
@@ -177,8 +183,8 @@ struct VerifyImpl {
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
         const unsigned hb = cdiv(count, FIXED_BLOCK);
         uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), 0, st, s, w_sc,
-                           v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
+        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
+                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
         const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);   // partials per proof after the fold
@@ -251,7 +257,7 @@ struct VerifyImpl {
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(L.fixed_blocks), dim3(FIXED_BLOCK), FIXED_BLOCK * JW * 4, st, s,
+        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
                            w_cs, v->table.u32(), w_fp, L.fixed_blocks, 0u, (const uint32_t*)nullptr,
                            (uint32_t*)nullptr, (size_t)0);
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
@@ -307,7 +313,7 @@ struct VerifyImpl {
             hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
                                d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
             hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
-                               FIXED_BLOCK * JW * 4, st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per, 0u,
+                               fixed_lds<C>(), st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per, 0u,
                                (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
             hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
                                d_pts.u32(), d_V.u32(), nv_total);

@@ -595,12 +595,6 @@ __global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __res
 
 // ---- the verification MulVec ---------------------------------------------------------------------------
 
-// Fixed-generator part: for proof b = blockIdx.y, sum_f scalar_f * F_f through the window tables.
-// scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
-// one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
-// that.  partials: ROLE 0: [count][per][blockDim.x] jacobians (one per thread, summed by k_partials_fold);
-// ROLE 1: [count][per] (block sums).
-// ROLE only separates the launches in profiles: 0 = the batch verifier's hot path, 1 = prover / combined check.
 // Last stage of the proof-point MSM (see k_var_tables / k_var_windows below), one lane per proof:
 // out[b] = sum_j 16^j * wsum[b][j] by Horner's rule -- 256 doublings that can only run one after the other.
 // Alone on the chip this is 128 waves of pure latency, so it does not get a launch of its own: the first
@@ -622,6 +616,44 @@ __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsu
     jac_stg<C>(out + b * JW, acc);
 }
 
+// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane copies 16 bytes from ITS OWN global address to
+// lds_byte_addr + lane * 16 (lds_byte_addr wave-uniform).  No VGPR destination, and -- being inline asm -- not
+// part of the compiler's s_waitcnt bookkeeping: the caller counts completions itself (vmcnt retires in order).
+__device__ __forceinline__ void glds16(const uint32_t* gsrc, uint32_t lds_byte_addr) {
+    unsigned keep;
+    lds_byte_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);   // M0 is scalar: make the uniformity explicit
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+
+// table entries in flight per lane, and the LDS they land in: per wave FIXED_RING slots of 2N/4 pieces of 1 KiB
+// (64 lanes x 16 B) + 2 pieces for the next generator's scalar
+#ifndef BPP_FIXED_RING
+#define BPP_FIXED_RING 2
+#endif
+constexpr int FIXED_RING = BPP_FIXED_RING;
+template <class C>
+constexpr unsigned fixed_lds_bytes() {
+    return (FIXED_BLOCK / 64) * (FIXED_RING * (2 * C::Fp::N / 4) + 2) * 1024;
+}
+
+// Fixed-generator part: for proof b, sum_f scalar_f * F_f through the window tables.
+// scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
+// one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
+// that.  partials: ROLE 0: [count][per][blockDim.x] jacobians (one per thread, summed by k_partials_fold);
+// ROLE 1: [count][per] (block sums).  ROLE also separates the launches in profiles: 0 = the batch verifier's
+// hot path, 1 = prover / combined check.
+//
+// Gathers: a wave retires one mixed addition every ~350 ns, a random 96-byte HBM read takes longer under load,
+// and the 220 VGPRs of the addition leave no room for a second set of landing registers.  So the entries do not
+// land in registers at all: they are LDS-DMA'd into a ring of FIXED_RING slots per lane, issued FIXED_RING
+// additions ahead, and read from LDS (ds_read_b128) at the moment of use.  All lanes of a block walk the same
+// (generator, window) sequence in lockstep -- a lane without an entry (zero digit, or past its last generator)
+// DMAs a dummy line -- so every step issues exactly 2N/4 DMA instructions per wave and a counted
+// s_waitcnt vmcnt((FIXED_RING-1) * 2N/4) is all the synchronisation the ring needs.  The next generator's
+// scalar travels the same way (2 pieces), one generator ahead.
 template <class C, int ROLE = 0>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per,
@@ -629,6 +661,8 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
                             size_t horner_count) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
+    constexpr int CH = 2 * N / 4;                              // 16-byte pieces of a table entry
+    constexpr int WAVE_WORDS = (FIXED_RING * CH + 2) * 256;    // LDS words of one wave's ring + scalar buffer
     extern __shared__ __align__(16) uint32_t lds[];
     if (blockIdx.x < horner_blocks) {   // block-uniform: the Horner lanes of the proof-point MSM
         const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -642,62 +676,107 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
     const uint32_t* sc = scalars + b * (size_t)s.N * 8;
     const uint32_t mask = (1u << s.c) - 1u;
     const uint32_t stride = per * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* ring = lds + (threadIdx.x >> 6) * WAVE_WORDS;    // [slot][piece][lane][4 words]
+    uint32_t* sbuf = ring + FIXED_RING * CH * 256;             // [2][lane][4 words]
+    const uint32_t ring_addr = (uint32_t)reinterpret_cast<uintptr_t>(ring);   // LDS byte address (low 32 bits)
+    const uint32_t sbuf_addr = ring_addr + FIXED_RING * CH * 1024;
+    const uint32_t f0 = part * blockDim.x + threadIdx.x;
+    const uint32_t first = part * blockDim.x;
+    const uint32_t G = first < s.NF ? (s.NF - 1 - first) / stride + 1 : 0;   // generators of the block's busiest lane
+    const uint32_t T = G * s.W;                                              // steps, the same for every lane
     Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
-    // software pipeline: the table entry of step t+1 is gathered while the mixed addition of step t runs, and
-    // the scalar of the NEXT generator is loaded while the windows of the current one are consumed (a load
-    // issued at the point of use would expose its full latency once per generator, i.e. every W additions)
-    uint32_t f = part * blockDim.x + threadIdx.x;
-    uint32_t j = s.W;  // forces the first scalar to be taken from `wn`
-    uint32_t w[10], wn[8];
-    if (f < s.NF) ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, wn);
-    bool have = false;   // a prefetched entry is pending
-    bool nneg = false;   // ... and must be negated when consumed
-    uint32_t raw[2 * N]; // its packed words, untouched until consumption so the gather stays in flight
-    auto fetch = [&]() {
-        have = false;
-        while (true) {
-            if (j == s.W) {
-                if (f >= s.NF) return;
-                // + bias K = sum_{j < W-1} half * 2^(c j): window j of (scalar + K) minus half is the signed digit
-                uint32_t carry = 0;
+
+    auto dma_scalar = [&](uint32_t g) {
+        const uint32_t f = f0 + g * stride;
+        const uint32_t* src = f < s.NF ? sc + (size_t)fixed_term_index(s, f) * 8 : sc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous scalar has been read out of sbuf
+        glds16(src, sbuf_addr);
+        glds16(src + 4, sbuf_addr + 1024);
+    };
+    uint32_t w[10];
+    auto take_scalar = [&]() {   // sbuf -> w = scalar + bias K (K = sum_{j < W-1} half * 2^(c j))
+        const uint4* q = reinterpret_cast<const uint4*>(sbuf);
+        const uint4 lo = q[lane], hi = q[64 + lane];
+        const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        uint32_t carry = 0;
 #pragma unroll
-                for (int t = 0; t < 10; t++) {
-                    uint64_t x = (uint64_t)(t < 8 ? wn[t] : 0u) + s.bias[t] + carry;
-                    w[t] = (uint32_t)x;
-                    carry = (uint32_t)(x >> 32);
-                }
-                if (f + stride < s.NF) ld_words<8>(sc + (size_t)fixed_term_index(s, f + stride) * 8, wn);
-                j = 0;
+        for (int t = 0; t < 10; t++) {
+            uint64_t x = (uint64_t)(t < 8 ? v[t] : 0u) + s.bias[t] + carry;
+            w[t] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
+    };
+    // issue side: runs FIXED_RING steps ahead of the additions
+    uint32_t ti = 0, gi = 0, ji = 0;   // step, generator iteration, window -- block-uniform
+    uint32_t vbits = 0, nbits = 0;     // per ring slot: this lane has an entry there / it must be negated
+    auto issue = [&]() {
+        const uint32_t slot = ti % FIXED_RING;
+        const uint32_t* src = table;   // dummy line for lanes without an entry
+        uint32_t valid = 0, neg = 0;
+        if (ti < T) {
+            if (ji == 0 && gi > 0) {
+                take_scalar();
+                if (gi + 1 < G) dma_scalar(gi + 1);
             }
+            const uint32_t f = f0 + gi * stride;
             // windows below the top: signed digit; top window: what is left of the value, unsigned (<= top)
-            const int32_t dg = j + 1 < s.W ? (int32_t)(w[0] & mask) - (int32_t)s.half : (int32_t)w[0];
+            const int32_t dg = ji + 1 < s.W ? (int32_t)(w[0] & mask) - (int32_t)s.half : (int32_t)w[0];
 #pragma unroll
             for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
             w[9] >>= s.c;
-            const uint32_t jj = j++;
-            const uint32_t ff = f;
-            if (j == s.W) f += stride;
-            if (dg != 0) {
+            if (f < s.NF && dg != 0) {
                 const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
-                ld_words<2 * N>(table + ((size_t)ff * s.per_f + (size_t)jj * s.half + (mag - 1)) * 2 * N, raw);
-                nneg = dg < 0;
-                have = true;
-                return;
+                src = table + ((size_t)f * s.per_f + (size_t)ji * s.half + (mag - 1)) * 2 * N;
+                valid = 1;
+                neg = dg < 0 ? 1u : 0u;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous entry has been read out
+#pragma unroll
+        for (int k = 0; k < CH; k++) glds16(src + 4 * k, ring_addr + (slot * CH + k) * 1024);
+        vbits = (vbits & ~(1u << slot)) | (valid << slot);
+        nbits = (nbits & ~(1u << slot)) | (neg << slot);
+        ti++;
+        if (++ji == s.W) {
+            ji = 0;
+            gi++;
+        }
     };
-    fetch();
-    while (have) {
-        Aff<C> cur = aff_load<C>(raw);
-        if (nneg) cur = aff_neg(cur);
-        fetch();
-        acc = xyzz_madd(acc, cur);
+    if (G) {
+        dma_scalar(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        take_scalar();
+        if (G > 1) dma_scalar(1);
     }
+    for (int d = 0; d < FIXED_RING; d++) issue();
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t slot = t % FIXED_RING;
+        // everything but the newest FIXED_RING - 1 steps' DMAs has landed: step t's entry is in LDS
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FIXED_RING - 1) * CH) : "memory");
+        uint32_t raw[2 * N];
+        const uint4* q = reinterpret_cast<const uint4*>(ring + slot * CH * 256);
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const uint4 v = q[k * 64 + lane];
+            raw[4 * k] = v.x;
+            raw[4 * k + 1] = v.y;
+            raw[4 * k + 2] = v.z;
+            raw[4 * k + 3] = v.w;
+        }
+        const bool valid = (vbits >> slot) & 1u;
+        Aff<C> cur = aff_load<C>(raw);
+        if ((nbits >> slot) & 1u) cur = aff_neg(cur);
+        issue();   // step t + FIXED_RING goes into the slot just read
+        if (valid) acc = xyzz_madd(acc, cur);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs have landed: LDS may be reused
     if (ROLE == 0) {
         // one partial per THREAD: a tree reduction here would run 7 jacobian additions with most lanes idle
         // (~4.5 % of the block's time); k_partials_fold sums them with every lane busy
         jac_stg<C>(partials + ((size_t)bid * blockDim.x + threadIdx.x) * JW, xyzz_to_jac(acc));
     } else {
+        __syncthreads();
         Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
         if (threadIdx.x == 0) jac_stg<C>(partials + (size_t)bid * JW, sum);
     }
