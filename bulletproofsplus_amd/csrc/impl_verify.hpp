@@ -43,10 +43,11 @@ constexpr unsigned fixed_lds() {
     return std::max<unsigned>(fixed_lds_bytes<C>(), FIXED_BLOCK * jac_words<C>() * 4);
 }
 
-constexpr unsigned FOLD_GROUP = 8;   // thread partials summed by one lane of k_partials_fold
+constexpr unsigned FOLD_GROUP = 8;    // thread partials summed by one lane of k_partials_fold (first pass)
+constexpr unsigned FOLD_GROUP2 = 4;   // ... and of the second pass
 
 struct WsLayout {
-    size_t pts, bad, scalars, fthread, fpart, vpart, vdig, vwsum, vtbl, vscr, total;
+    size_t pts, bad, scalars, fthread, fpart, fpart2, vpart, vdig, vwsum, vtbl, vscr, total;
 };
 
 template <class C>
@@ -70,6 +71,8 @@ struct VerifyImpl {
         o += al(count * blocks_per_proof(s, count) * FIXED_BLOCK * JW * 4);                // one partial per thread
         w.fpart = o;
         o += al(count * blocks_per_proof(s, count) * (FIXED_BLOCK / FOLD_GROUP) * JW * 4);  // folded 8 to 1
+        w.fpart2 = o;
+        o += al(count * blocks_per_proof(s, count) * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2) * JW * 4);  // then 4 to 1
         w.vpart = o;
         o += al(count * JW * 4);                                   // one jacobian per proof
         w.vdig = o;
@@ -112,13 +115,20 @@ struct VerifyImpl {
             return fail(BPP_E_NOMEM, std::string("window table allocation failed: ") + hipGetErrorString(e));
         }
         hipLaunchKernelGGL(k_tbl_bases<C>, dim3(cdiv(s.NF, 64)), dim3(64), 0, nullptr, s, dfixed.u32(), v->table.u32());
-        // fill in slabs of generators so that one launch stays well below 2^31 blocks
-        const size_t per_f = s.per_f;
-        const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 28) / per_f);
+        // fill in slabs of generators: one thread per run of TBL_RUN entries, 2 * TBL_RUN field elements of scratch each
+        const uint32_t runs_f = tbl_runs_per_generator(s);
+        const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 21) / runs_f);
+        DevBuf tbl_scratch;
+        e = tbl_scratch.alloc((size_t)std::min<uint32_t>(slab, s.NF) * runs_f * 2 * TBL_RUN * N * 4);
+        if (e != hipSuccess) {
+            delete v;
+            return fail(BPP_E_NOMEM, std::string("table scratch allocation failed: ") + hipGetErrorString(e));
+        }
         for (uint32_t f0 = 0; f0 < s.NF; f0 += slab) {
             const uint32_t f1 = std::min<uint32_t>(s.NF, f0 + slab);
-            const size_t total = (size_t)(f1 - f0) * per_f;
-            hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 128)), dim3(128), 0, nullptr, s, v->table.u32(), f0, f1);
+            const size_t total = (size_t)(f1 - f0) * runs_f;
+            hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, s, v->table.u32(),
+                               tbl_scratch.u32(), f0, f1);
         }
         std::vector<uint32_t> ch;
         default_challenges(s, ch);
@@ -187,10 +197,15 @@ struct VerifyImpl {
                            w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
-        const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);   // partials per proof after the fold
+        // 128 per-thread partials per block -> 16 -> 4, every lane of the fold kernels busy; k_finalize adds the rest
+        const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);
+        const unsigned folded2 = folded / FOLD_GROUP2;
+        uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
         hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
                            count * folded);
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp, folded, w_vp, 1u,
+        hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
+                           count * folded2);
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp2, folded2, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());

@@ -554,6 +554,53 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
 
 // ---- window tables -------------------------------------------------------------------------------------
 
+// J, J + step, J + 2 step, ... (count points) as AFFINE points in out[0 .. count-1]: a chain of mixed additions
+// in projective coordinates, then ONE inversion (safegcd) of the product of all Z's and a backward pass
+// (Montgomery's trick) -- ~19 field multiplications per point instead of an inversion each.  While the chain runs,
+// X | Y are parked in the output slot itself and Z with the running product in scratch[0 .. 2 count) (N words
+// each).  A Weierstrass point outside the prime-order subgroup (BLS12-381 G1 has cofactor 3 * 11^2 * ...) can
+// reach infinity inside the chain: such a point is parked as x = y = 0 with Z = 1, so the product stays
+// invertible and the scaled entry is the infinity encoding.  (Edwards: Z is never 0.)
+template <class C>
+__device__ __forceinline__ void affine_chain(Jac<C> J, const Aff<C>& step, uint32_t count, uint32_t* __restrict__ out,
+                                             uint32_t* __restrict__ scratch) {
+    using P = typename C::Fp;
+    using F = Fe<P>;
+    constexpr int N = P::N;
+    F run = F::one();
+    uint32_t w[N];
+    for (uint32_t k = 0; k < count; k++) {
+        if (k > 0) J = jac_madd(J, step);
+        const bool at_inf = C::ID != 2 && J.is_inf();
+        const F z = at_inf ? F::one() : J.Z;
+        run = fe_mul(run, z);
+        fe_store(at_inf ? F::zero() : J.X, w);
+        st_words<N>(out + (size_t)k * 2 * N, w);
+        fe_store(at_inf ? F::zero() : J.Y, w);
+        st_words<N>(out + (size_t)k * 2 * N + N, w);
+        fe_store(z, w);
+        st_words<N>(scratch + (size_t)k * N, w);
+        fe_store(run, w);
+        st_words<N>(scratch + (size_t)(count + k) * N, w);
+    }
+    F inv = fe_inv(run);   // (Z_0 ... Z_{count-1})^-1
+    for (uint32_t k = count; k-- > 0;) {
+        F zi = inv;
+        if (k > 0) {
+            ld_words<N>(scratch + (size_t)(count + k - 1) * N, w);   // product of the Z's before k
+            zi = fe_mul(inv, fe_load<P>(w));
+            ld_words<N>(scratch + (size_t)k * N, w);
+            inv = fe_mul(inv, fe_load<P>(w));
+        }
+        Jac<C> q = J;   // only X and Y are read by jac_scale_to_aff
+        ld_words<N>(out + (size_t)k * 2 * N, w);
+        q.X = fe_load<P>(w);
+        ld_words<N>(out + (size_t)k * 2 * N + N, w);
+        q.Y = fe_load<P>(w);
+        aff_stg<C>(out + (size_t)k * 2 * N, jac_scale_to_aff(q, zi));
+    }
+}
+
 // thread f: base_{f,j} = 2^(c j) * F_f for every window j, written as entry d = 1
 template <class C>
 __global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t* __restrict__ fixed_pts, uint32_t* __restrict__ table) {
@@ -572,25 +619,37 @@ __global__ void __launch_bounds__(64) k_tbl_bases(VerifyShape s, const uint32_t*
     }
 }
 
-// one thread per entry: entry d = d * base (d = 2..half), affine
+// one thread per RUN of TBL_RUN consecutive entries of one window: d0 * base by double-and-add, then
+// (d0 + 1) * base, ... by affine_chain.  scratch: [thread][2 * TBL_RUN] field elements.
+constexpr uint32_t TBL_RUN = 32;
+__host__ __device__ __forceinline__ uint32_t tbl_runs_per_generator(const VerifyShape& s) {
+    return (s.W - 1) * ((s.half + TBL_RUN - 1) / TBL_RUN) + (s.top + TBL_RUN - 1) / TBL_RUN;
+}
 template <class C>
-__global__ void __launch_bounds__(128) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t f_begin, uint32_t f_end) {
+__global__ void __launch_bounds__(64, 2) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t* __restrict__ scratch,
+                                                    uint32_t f_begin, uint32_t f_end) {
     constexpr int N = C::Fp::N;
-    constexpr int JW = jac_words<C>();
-    const size_t per_f = s.per_f;
+    const uint32_t runs_low = (s.half + TBL_RUN - 1) / TBL_RUN;
+    const uint32_t runs_f = tbl_runs_per_generator(s);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(f_end - f_begin) * per_f;
-    if (idx >= total) return;
-    const size_t e = (size_t)f_begin * per_f + idx;
-    const uint32_t in_f = (uint32_t)(idx % per_f);
-    const uint32_t j = min(in_f / s.half, s.W - 1);   // the top window may hold more than `half` entries
-    const uint32_t d = in_f - j * s.half + 1;
-    if (d == 1) return;
-    const size_t base_e = e - (d - 1);
-    Aff<C> base = aff_ldg<C>(table + base_e * 2 * N);
-    uint32_t kw[1] = {d};
-    Jac<C> r = aff_mul_words(base, kw, 1);
-    aff_stg<C>(table + e * 2 * N, jac_to_aff(r));
+    if (idx >= (size_t)(f_end - f_begin) * runs_f) return;
+    const uint32_t f = f_begin + (uint32_t)(idx / runs_f);
+    const uint32_t rem = (uint32_t)(idx % runs_f);
+    const uint32_t j = min(rem / runs_low, s.W - 1);   // the top window has its own number of runs
+    const uint32_t r = rem - j * runs_low;
+    const uint32_t cnt = j + 1 < s.W ? s.half : s.top;
+    const uint32_t d0 = r * TBL_RUN + 1;
+    const uint32_t n = min(TBL_RUN, cnt - (d0 - 1));
+    uint32_t* win = table + ((size_t)f * s.per_f + (size_t)j * s.half) * 2 * N;
+    const Aff<C> base = aff_ldg<C>(win);   // entry d = 1, written by k_tbl_bases
+    Jac<C> J;
+    if (d0 == 1) {
+        J = jac_from_aff(base);
+    } else {
+        uint32_t kw[1] = {d0};
+        J = aff_mul_words(base, kw, 1);
+    }
+    affine_chain<C>(J, base, n, win + (size_t)(d0 - 1) * 2 * N, scratch + idx * 2 * TBL_RUN * N);
 }
 
 // ---- the verification MulVec ---------------------------------------------------------------------------
@@ -681,10 +740,16 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
     uint32_t* sbuf = ring + FIXED_RING * CH * 256;             // [2][lane][4 words]
     const uint32_t ring_addr = (uint32_t)reinterpret_cast<uintptr_t>(ring);   // LDS byte address (low 32 bits)
     const uint32_t sbuf_addr = ring_addr + FIXED_RING * CH * 1024;
-    const uint32_t f0 = part * blockDim.x + threadIdx.x;
+    const uint32_t f0 = part * blockDim.x + threadIdx.x;   // the lane's index among the proof's `stride` lanes
     const uint32_t first = part * blockDim.x;
-    const uint32_t G = first < s.NF ? (s.NF - 1 - first) / stride + 1 : 0;   // generators of the block's busiest lane
-    const uint32_t T = G * s.W;                                              // steps, the same for every lane
+    // Every lane takes G whole generators (f0, f0 + stride, ...).  The NF mod stride generators that are left
+    // (g and h at n=64, m=16: 2050 = 16 * 128 + 2) are not given to two lanes as a 17th generator -- their waves
+    // would run 6 % longer than the rest -- but spread window by window over all lanes in E extra steps.
+    const bool spread = s.NF >= stride;
+    const uint32_t G = spread ? s.NF / stride : (first < s.NF ? 1u : 0u);
+    const uint32_t T = G * s.W;                                    // whole-generator steps, the same for every lane
+    const uint32_t LW = spread ? (s.NF - G * stride) * s.W : 0u;   // left-over (generator, window) entries of the proof
+    const uint32_t TT = T + (LW + stride - 1) / stride;            // + extra steps
     Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
 
     auto dma_scalar = [&](uint32_t g) {
@@ -731,6 +796,35 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
                 valid = 1;
                 neg = dg < 0 ? 1u : 0u;
             }
+        } else if (ti < TT) {
+            const uint32_t x = (ti - T) * stride + f0;   // this lane's left-over entry, if any
+            if (x < LW) {
+                const uint32_t l = x / s.W, jx = x - l * s.W;
+                const uint32_t f = G * stride + l;
+                uint32_t we[10];
+                ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, we);   // an ordinary load: once per block
+                we[8] = 0;
+                we[9] = 0;
+                uint32_t carry = 0;
+#pragma unroll
+                for (int t = 0; t < 10; t++) {
+                    uint64_t v = (uint64_t)we[t] + s.bias[t] + carry;
+                    we[t] = (uint32_t)v;
+                    carry = (uint32_t)(v >> 32);
+                }
+                for (uint32_t r = 0; r < jx; r++) {
+#pragma unroll
+                    for (int t = 0; t < 9; t++) we[t] = (we[t] >> s.c) | (we[t + 1] << (32 - s.c));
+                    we[9] >>= s.c;
+                }
+                const int32_t dg = jx + 1 < s.W ? (int32_t)(we[0] & mask) - (int32_t)s.half : (int32_t)we[0];
+                if (dg != 0) {
+                    const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
+                    src = table + ((size_t)f * s.per_f + (size_t)jx * s.half + (mag - 1)) * 2 * N;
+                    valid = 1;
+                    neg = dg < 0 ? 1u : 0u;
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous entry has been read out
 #pragma unroll
@@ -750,7 +844,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
         if (G > 1) dma_scalar(1);
     }
     for (int d = 0; d < FIXED_RING; d++) issue();
-    for (uint32_t t = 0; t < T; t++) {
+    for (uint32_t t = 0; t < TT; t++) {
         const uint32_t slot = t % FIXED_RING;
         // everything but the newest FIXED_RING - 1 steps' DMAs has landed: step t's entry is in LDS
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FIXED_RING - 1) * CH) : "memory");
@@ -856,43 +950,7 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_tables(const u
         for (int k = 1; k < M; k++) aff_stg<C>(T + (size_t)k * 2 * N, p);
         return;
     }
-    // k P in projective coordinates; X | Y parked in the table slot, Z and the running product of Z's in scratch
-    // A Weierstrass point outside the prime-order subgroup (BLS12-381 G1 has cofactor 3 * 11^2 * ...) can reach
-    // infinity inside the chain: such a multiple is parked as x = y = 0 with Z = 1, so the product of the Z's
-    // stays invertible and the scaled entry is the infinity encoding.  (Edwards: Z is never 0.)
-    Jac<C> J = aff_dbl(p);
-    F run = F::one();
-    uint32_t w[N];
-    for (int k = 1; k < M; k++) {
-        if (k > 1) J = jac_madd(J, p);
-        const bool at_inf = C::ID != 2 && J.is_inf();
-        const F z = at_inf ? F::one() : J.Z;
-        run = fe_mul(run, z);
-        fe_store(at_inf ? F::zero() : J.X, w);
-        st_words<N>(T + (size_t)k * 2 * N, w);
-        fe_store(at_inf ? F::zero() : J.Y, w);
-        st_words<N>(T + (size_t)k * 2 * N + N, w);
-        fe_store(z, w);
-        st_words<N>(S + (size_t)(k - 1) * N, w);
-        fe_store(run, w);
-        st_words<N>(S + (size_t)(M - 1 + k - 1) * N, w);
-    }
-    F inv = fe_inv(run);   // (Z_2 ... Z_8)^-1
-    for (int k = M - 1; k >= 1; k--) {
-        F zi = inv;
-        if (k > 1) {
-            ld_words<N>(S + (size_t)(M - 1 + k - 2) * N, w);   // prefix product up to k - 1
-            zi = fe_mul(inv, fe_load<P>(w));
-            ld_words<N>(S + (size_t)(k - 1) * N, w);
-            inv = fe_mul(inv, fe_load<P>(w));
-        }
-        Jac<C> q = J;   // only X and Y are read by jac_scale_to_aff
-        ld_words<N>(T + (size_t)k * 2 * N, w);
-        q.X = fe_load<P>(w);
-        ld_words<N>(T + (size_t)k * 2 * N + N, w);
-        q.Y = fe_load<P>(w);
-        aff_stg<C>(T + (size_t)k * 2 * N, jac_scale_to_aff(q, zi));
-    }
+    affine_chain<C>(aff_dbl(p), p, M - 1, T + 2 * N, S);   // 2P .. 8P
 }
 
 // lane = (proof b, window j): wsum[lane] = sum_v sign * T[b][v][|digit| - 1]
