@@ -393,6 +393,11 @@ def test_full_size_batch_round_trip_properties():
         verdicts.append(v)
         assert run_combined_device(torch, eng, recs, sc, 3 + c)[0] == 0
         assert run_combined_device(torch, eng, dirty_recs, dirty_sc, 3 + c)[0] == 1
+        if c == 14:
+            # 768 proofs: three blocks per proof (stride 384), so 130 of the 2 050 generators are left over and
+            # are spread over the lanes in 6 extra steps of k_fixed_msm; 256 proofs above: 8 blocks, 1 extra step
+            v3 = eng.verify_wire(np.tile(dirty_recs, (3, 1, 1)), np.tile(dirty_sc, (3, 1, 1))).tolist()
+            assert v3 == v * 3
         eng.close()
     assert verdicts[0] == verdicts[1]
 
