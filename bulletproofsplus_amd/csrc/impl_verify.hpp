@@ -30,11 +30,17 @@ struct bpp_verifier {
 namespace bpp {
 
 inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
-    // aim at ~2^18 resident threads; at least one block, at most one generator per thread
+    const unsigned maxb = cdiv(s.NF, FIXED_BLOCK);
+    // small batches: aim at ~2^18 resident threads; at least one block, at most one generator per thread
     size_t tpp = ((size_t)1 << 18) / (count ? count : 1);
     tpp = std::max<size_t>(FIXED_BLOCK, std::min<size_t>(tpp, s.NF));
-    unsigned b = cdiv(tpp, FIXED_BLOCK);
-    return std::max(1u, std::min(b, cdiv(s.NF, FIXED_BLOCK)));
+    const unsigned b_lat = cdiv(tpp, FIXED_BLOCK);
+    // large batches: the chip holds 1024 blocks at a time, and a launch of only a few such rounds ends with a
+    // long, mostly idle tail (8 rounds of 5 ms blocks: the last 3.5 ms ran 64 blocks).  Aim at >= 32 rounds,
+    // but keep at least four generators per lane so that a block's prologue stays amortised.
+    const unsigned b_thr = std::min<unsigned>(cdiv((size_t)32768, count ? count : 1),
+                                              std::max<unsigned>(1, s.NF / (FIXED_BLOCK * 4)));
+    return std::max(1u, std::min(std::max(b_lat, b_thr), maxb));
 }
 
 // dynamic LDS of a k_fixed_msm launch: the gather ring, reused by the block reduction of ROLE 1
@@ -47,7 +53,7 @@ constexpr unsigned FOLD_GROUP = 8;    // thread partials summed by one lane of k
 constexpr unsigned FOLD_GROUP2 = 4;   // ... and of the second pass
 
 struct WsLayout {
-    size_t pts, bad, scalars, fthread, fpart, fpart2, vpart, vdig, vwsum, vtbl, vscr, total;
+    size_t pts, bad, scalars, fthread, fpart, fpart2, fpart3, vpart, vdig, vwsum, vtbl, vscr, total;
 };
 
 template <class C>
@@ -73,6 +79,8 @@ struct VerifyImpl {
         o += al(count * blocks_per_proof(s, count) * (FIXED_BLOCK / FOLD_GROUP) * JW * 4);  // folded 8 to 1
         w.fpart2 = o;
         o += al(count * blocks_per_proof(s, count) * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2) * JW * 4);  // then 4 to 1
+        w.fpart3 = o;
+        o += al(count * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2) * JW * 4);   // then the blocks of a proof: 4 per proof
         w.vpart = o;
         o += al(count * JW * 4);                                   // one jacobian per proof
         w.vdig = o;
@@ -197,7 +205,8 @@ struct VerifyImpl {
                            w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
-        // 128 per-thread partials per block -> 16 -> 4, every lane of the fold kernels busy; k_finalize adds the rest
+        // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
+        // k_finalize adds the rest
         const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);
         const unsigned folded2 = folded / FOLD_GROUP2;
         uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
@@ -205,7 +214,16 @@ struct VerifyImpl {
                            count * folded);
         hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
                            count * folded2);
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_fp2, folded2, w_vp, 1u,
+        const uint32_t* w_last = w_fp2;
+        unsigned last = folded2;
+        if (bpp_ > 1) {   // several blocks per proof: one more pass, so that k_finalize always sees 4 partials
+            uint32_t* w_fp3 = reinterpret_cast<uint32_t*>(ws + L.fpart3);
+            last = folded2 / bpp_;
+            hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * last, 64)), dim3(64), 0, st, w_fp2, bpp_, w_fp3,
+                               count * last);
+            w_last = w_fp3;
+        }
+        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_last, last, w_vp, 1u,
                            w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());
