@@ -102,12 +102,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (not used by the driver): BPP_BENCH_BACKEND=gloo and BPP_BENCH_DEVICE=0 let two ranks share
+    # the one GPU of a development box, to exercise the world > 1 control flow without RCCL
+    backend = os.environ.get("BPP_BENCH_BACKEND", "nccl")
+    if "BPP_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BPP_BENCH_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
