@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--cpu-per-thread", type=int, default=2)
     ap.add_argument("--combined-steps", type=int, default=-1,
                     help="extra (separately timed) steps of the combined batch check; -1 = same as --steps, 0 = skip")
+    ap.add_argument("--hard-steps", type=int, default=4,
+                    help="steps of the 'hard distribution' leg (random generators, random full-width challenges; SURVEY 8d); 0 = skip")
     args = ap.parse_args()
 
     import numpy as np
@@ -236,8 +238,85 @@ def main():
                 "note": "random-linear-combination batch check (SplitMix64 weights): batch verdict only, NOT the "
                         "reference's per-proof verdicts; reported beside `value`, never as it"}
 
+    # ---- secondary, separately timed: the "hard" distribution of SURVEY.md 8d.  Generators are random multiples
+    # of g (SplitMix64 stream) instead of PublicKey::new's small multiples, and every proof is verified under its
+    # own uniformly random full-width challenges instead of the reference's tiny constants.  Under random
+    # challenges the proofs no longer verify -- the pass does exactly the same work either way (no early exit), so
+    # this leg reports a rate, not verdicts; with the default challenges the same proofs are first checked to be Ok.
+    hard = None
+    msm_len_main, table_bytes_main = bv.msm_len, bv.table_bytes
+    if args.hard_steps > 0:
+        order = {"bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+                 "secp256k1": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+                 "ed25519": (1 << 252) + 27742317777372353535851937790883648493}[args.curve]
+        state = [0xB0117E7 + 7919 * rank]
+
+        def splitmix():
+            state[0] = (state[0] + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            z = state[0]
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            return z ^ (z >> 31)
+
+        def rand_scalar():
+            return ((splitmix() << 192) | (splitmix() << 128) | (splitmix() << 64) | splitmix()) % order
+
+        bv.close()                                  # the second set of tables needs the HBM of the first
+        del d_ws
+        torch.cuda.empty_cache()
+        nf = 2 * n * m + 2
+        ks = [rand_scalar() or 1 for _ in range(nf)]
+        gens = a.scalar_mul(ks, np.repeat(pk.gh[:1], nf, axis=0))
+        pk_h = B.PublicKey.from_points(a, gens[:2], gens[2:2 + n * m], gens[2 + n * m:])
+        bv_h = B.BatchVerifier(pk_h, n, m, window_bits=args.window)
+        pts_h, scs_h, V_h = bv_h.prove_batch(vals, gams)
+        recs_h = np.ascontiguousarray(np.concatenate([pts_h, V_h], axis=1))
+        if D < Bsz:
+            recs_h = np.ascontiguousarray(recs_h[np.arange(Bsz) % D])
+            scs_h = np.ascontiguousarray(scs_h[np.arange(Bsz) % D])
+        d_pts_h = torch.from_numpy(recs_h.view(np.int64)).to(dev)
+        d_sc_h = torch.from_numpy(np.ascontiguousarray(scs_h).view(np.int64)).to(dev)
+        wsb_h = bv_h.workspace_bytes(Bsz)
+        d_ws_h = torch.empty(wsb_h, dtype=torch.uint8, device=dev)
+        kk = (n * m).bit_length() - 1
+        ch = np.zeros((Bsz, 3 + kk, 4), dtype=np.uint64)
+        rs = np.random.RandomState(12345 + rank)
+        ch[:, :, :3] = rs.randint(0, 2**63, size=(Bsz, 3 + kk, 3), dtype=np.int64).astype(np.uint64) * np.uint64(2) + \
+            rs.randint(0, 2, size=(Bsz, 3 + kk, 3)).astype(np.uint64)
+        ch[:, :, 3] = rs.randint(1, 2**60, size=(Bsz, 3 + kk), dtype=np.int64).astype(np.uint64)   # < 2^252 <= every order
+        d_ch = torch.from_numpy(ch.view(np.int64)).to(dev)
+        bv_h.run_device(d_pts_h.data_ptr(), d_sc_h.data_ptr(), Bsz, d_ok.data_ptr(), d_ws_h.data_ptr(), wsb_h, stream)
+        torch.cuda.synchronize()
+        assert int(d_ok.sum().item()) == 0, "hard distribution: a valid proof failed under the default challenges"
+        bv_h.run_device(d_pts_h.data_ptr(), d_sc_h.data_ptr(), Bsz, d_ok.data_ptr(), d_ws_h.data_ptr(), wsb_h, stream,
+                        d_challenges=d_ch.data_ptr())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        for _ in range(args.hard_steps):
+            bv_h.run_device(d_pts_h.data_ptr(), d_sc_h.data_ptr(), Bsz, d_ok.data_ptr(), d_ws_h.data_ptr(), wsb_h, stream,
+                            d_challenges=d_ch.data_ptr())
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        hdt = time.perf_counter() - th0
+        rejected = int((d_ok != 0).sum().item())
+        if dist is not None:
+            tmax = torch.tensor([hdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            hdt = float(tmax.item())
+        hard = {"value": world * Bsz * args.hard_steps / hdt, "unit": "verifies/s", "steps": args.hard_steps,
+                "ms_per_step": hdt / args.hard_steps * 1e3, "rejected_under_random_challenges": rejected,
+                "note": "random generators k_i*g (SplitMix64) and per-proof uniformly random full-width challenges (y, z, e, e_1..e_k) "
+                        "through d_challenges: every MulVec scalar is full width; the proofs were made for the default "
+                        "challenges, so they are rejected here -- the pass does the same work for valid and invalid proofs"}
+        bv_h.close()
+
     if rank == 0:
-        N_msm = bv.msm_len
+        N_msm = msm_len_main
         NF = 2 * n * m + 2
         fp_bytes = (a.PW - 1) // 2 * 8
         term_bytes = 2 * fp_bytes + 32                      # affine point + scalar
@@ -274,7 +353,7 @@ def main():
             "data": "synthetic: %d distinct GPU-proved proofs per GPU in a batch of %d; reference constants as transcript" % (D, Bsz),
             "config": {"workload": "n=%d m=%d aggregated range-proof verify, %s, batch %d per GPU, per-proof verdicts" % (n, m, args.curve, Bsz),
                        "curve": args.curve, "msm_terms_per_verify": N_msm, "window_bits": args.window,
-                       "table_bytes": bv.table_bytes, "parallelism": "proof-sharded x%d" % world},
+                       "table_bytes": table_bytes_main, "parallelism": "proof-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_fixed_msm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms, "launches_timed": passes,
@@ -286,6 +365,7 @@ def main():
                          "note": "integer-ALU bound, not HBM bound (DESIGN.md section 4): `alu` is the meaningful ceiling"},
             "stage_ms": stage_ms,
             "combined_check": comb,
+            "hard_distribution": hard,
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},
         }
         thr = args.cpu_threads
