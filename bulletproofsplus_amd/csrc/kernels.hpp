@@ -17,11 +17,14 @@
 //   k_jac_reduce         sums jacobian partials of one MulVec -> wire point
 //   k_verify_scalars     all verifier scalars of one proof      wip.rs:330-382, range/mod.rs:417-477, :198-226,
 //                                                               wip.rs:254-295
-//   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums)
-//                                                               range/mod.rs:480-503 / wip.rs:297-320
-//   k_var_digits/tables/windows (+ Horner lanes inside k_fixed_msm)  the 3+2k+m proof-dependent terms of the same MulVec (Straus per proof)
+//   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums, LDS-DMA
+//                        gather ring, one partial per thread); its leading blocks run the Horner lanes of the
+//                        proof-point MulVec                    range/mod.rs:480-503 / wip.rs:297-320
+//   k_partials_fold      dense sums of the per-thread partials
+//   k_var_digits/tables/windows  the 3+2k+m proof-dependent terms of the same MulVec (Straus per proof)
 //   k_finalize           sum of partials, is_zero -> verdict    range/mod.rs:505-509, wip.rs:323-327
-//   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new)
+//   k_tbl_bases/k_tbl_fill  builds the window tables (setup, like PublicKey::new); affine_chain is the shared
+//                        "chain of mixed additions + one inversion" of k_tbl_fill and k_var_tables
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec.hpp"

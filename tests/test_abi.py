@@ -76,3 +76,15 @@ def test_host_field_arithmetic_matches_bigints():
         lines.append("%s mul %x 3" % (f, top)); exp.append(top * 3 % m)
     out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split()
     assert [int(o, 16) for o in out] == exp
+
+
+def test_generated_constants_are_in_sync():
+    """csrc/constants_gen.h is what tools/gen_constants.py generates from the field moduli (Montgomery constants,
+    p^-1 mod 2^30, number of divstep batches, curve constants)."""
+    import subprocess
+    import sys
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "bpp_constants_check.h")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_constants.py"), out], stdout=subprocess.DEVNULL)
+    with open(out) as f, open(os.path.join(ROOT, "bulletproofsplus_amd", "csrc", "constants_gen.h")) as g:
+        assert f.read() == g.read()
