@@ -311,7 +311,7 @@ inline size_t vs_lds_bytes(const VerifyShape& s) {
 //   m = 1 (wip.rs:298-307)      : [1, e,    e^2,  g_exp, h_exp, e_i^2 e^2,  e_i^-2 e^2, G_exp (n),  H_exp (n),  V_exp (1)]
 // proof_scalars: [r', s', delta'] per proof; challenges: [y, z, e, e_1..e_k] (per proof when
 // ch_stride != 0, shared otherwise).
-// Phases: (A) one lane per proof inverts y, e, e_1..e_k with ONE Fermat inversion (Montgomery's trick);
+// Phases: (A) one lane per proof inverts y, e, e_1..e_k with ONE inversion (fe_inv: safegcd; Montgomery's trick for the rest);
 // (B) one lane per proof computes the per-proof constants, another the power tables; (B') the first
 // mn/64 lanes of each proof build three small per-proof tables; (C) 64 lanes per proof, mn/64 consecutive
 // indices each, three multiplications per index:

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
     uint32_t* vp0 = vps + p * (size_t)nvp * s.N * 8;
 
     if (tid == 0) {
-        // batched inversion of [y, e_1..e_k] (one Fermat inversion), power table y^(2^b)
+        // batched inversion of [y, e_1..e_k] (one fe_inv), power table y^(2^b)
         uint32_t w[8];
         ld_words<8>(ch, w);
         const F y = fe_from_canonical<P>(w);
