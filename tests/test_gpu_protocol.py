@@ -85,6 +85,8 @@ def test_prove_and_verify_reference_sizes(golden):
     ("secp256k1", 8, [200, 5], [3, 7], 7),
     ("secp256k1", 8, [77], [9], 3),
     ("bls12_381", 4, [9, 3, 15, 0], [1, 2, 3, 4], 6),
+    ("bls12_381", 8, [77], [9], 17),       # the bench's window width: 15 windows, unsigned top window of 118 k entries
+    ("secp256k1", 8, [77], [9], 16),       # 256-bit scalars: the top window is a full 16 bits wide
 ])
 def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
     """Batch of valid / tampered / out-of-range proofs: scalars, result point and verdict == oracle."""
