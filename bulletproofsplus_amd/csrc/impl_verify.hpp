@@ -223,8 +223,8 @@ struct VerifyImpl {
                                count * last);
             w_last = w_fp3;
         }
-        hipLaunchKernelGGL(k_finalize<C>, dim3((unsigned)count), dim3(64), 64 * JW * 4, st, w_last, last, w_vp, 1u,
-                           w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result));
+        hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_last, last, w_vp, 1u, w_bad, d_ok,
+                           reinterpret_cast<uint32_t*>(d_out_result), count);
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());
         return BPP_OK;

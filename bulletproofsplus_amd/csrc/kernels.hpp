@@ -708,10 +708,12 @@ constexpr unsigned fixed_lds_bytes() {
 // ROLE 1: [count][per] (block sums).  ROLE also separates the launches in profiles: 0 = the batch verifier's
 // hot path, 1 = prover / combined check.
 //
-// Gathers: a wave retires one mixed addition every ~350 ns, a random 96-byte HBM read takes longer under load,
-// and the 220 VGPRs of the addition leave no room for a second set of landing registers.  So the entries do not
-// land in registers at all: they are LDS-DMA'd into a ring of FIXED_RING slots per lane, issued FIXED_RING
-// additions ahead, and read from LDS (ds_read_b128) at the moment of use.  All lanes of a block walk the same
+// Gathers: a wave spends ~20 us on one mixed addition (7 300 instructions at two waves per SIMD), far longer than
+// a random 96-byte HBM read, so latency is not the issue -- registers are: 24 VGPRs of landing space for the
+// next entry and 8 for the next scalar sat on top of the ~200 the addition needs.  So the entries do not land in
+// registers at all: they are LDS-DMA'd into a ring of FIXED_RING slots per lane, issued FIXED_RING additions
+// ahead, and read from LDS (ds_read_b128) at the moment of use (229 -> 200 VGPRs, no vmcnt wait placed by the
+// compiler inside the loop; measured -2 % on the launch).  All lanes of a block walk the same
 // (generator, window) sequence in lockstep -- a lane without an entry (zero digit, or past its last generator)
 // DMAs a dummy line -- so every step issues exactly 2N/4 DMA instructions per wave and a counted
 // s_waitcnt vmcnt((FIXED_RING-1) * 2N/4) is all the synchronisation the ring needs.  The next generator's
@@ -992,31 +994,27 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
 }
 
 // expected = fixed part + proof part ; verdict = expected.is_zero() ? Ok : VerificationError
-// (range/mod.rs:503-509, wip.rs:320-327).  One wave per proof sums its `per` fixed partials and NV
-// proof-point products.  A proof with an invalid point is rejected.
+// (range/mod.rs:503-509, wip.rs:320-327).  One LANE per proof adds its few folded partials (`per` fixed ones and
+// `nv` from the proof points) one after the other: a wave per proof with a tree reduction spent six levels of
+// mostly idle lanes on five points.  A proof with an invalid point is rejected.
 template <class C>
 __global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fixed_partials, uint32_t per,
                                                  const uint32_t* __restrict__ var_partials, uint32_t nv,
                                                  const uint32_t* __restrict__ bad, uint32_t* __restrict__ ok,
-                                                 uint32_t* __restrict__ wire_result) {
+                                                 uint32_t* __restrict__ wire_result, size_t count) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
-    extern __shared__ __align__(16) uint32_t lds[];
-    const size_t b = blockIdx.x;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t t = threadIdx.x; t < per + nv; t += blockDim.x) {
-        const uint32_t* src = t < per ? fixed_partials + (b * per + t) * JW : var_partials + (b * nv + (t - per)) * JW;
-        acc = jac_add(acc, jac_ldg<C>(src));
-    }
-    acc = block_reduce_jac<C>(acc, lds);
-    if (threadIdx.x == 0) {
-        ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
-        if (wire_result) {
-            uint32_t w[2 * N + 2];
-            aff_to_wire(jac_to_aff(acc), w);
+    for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * JW));
+    for (uint32_t t = 0; t < nv; t++) acc = jac_add(acc, jac_ldg<C>(var_partials + (b * nv + t) * JW));
+    ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
+    if (wire_result) {
+        uint32_t w[2 * N + 2];
+        aff_to_wire(jac_to_aff(acc), w);
 #pragma unroll
-            for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
-        }
+        for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
     }
 }
 
