@@ -166,6 +166,30 @@ def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
     return out
 
 
+def compressed_bytes(arith: Arith) -> int:
+    """bytes of one compressed point (48 BLS12-381 G1, 33 secp256k1 SEC1; 0 = not offered)"""
+    return _lib.lib().bpp_point_compressed_bytes(arith.curve)
+
+
+def compress_points(arith: Arith, points) -> np.ndarray:
+    """wire points (n, PW) u64 -> (n, compressed_bytes) u8.  No reference counterpart (include/bpp_amd.h)."""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, arith.PW)
+    out = np.zeros((pts.shape[0], compressed_bytes(arith)), dtype=np.uint8)
+    check(_lib.lib().bpp_points_compress(arith.handle, _ptr(pts), pts.shape[0], _ptr(out)), "bpp_points_compress")
+    return out
+
+
+def decompress_points(arith: Arith, data):
+    """(n, compressed_bytes) u8 -> (wire points (n, PW) u64, ok (n,) u32: 0 valid / 1 malformed -> infinity)"""
+    cb = compressed_bytes(arith)
+    raw = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, cb)
+    pts = np.zeros((raw.shape[0], arith.PW), dtype=np.uint64)
+    ok = np.zeros(raw.shape[0], dtype=np.uint32)
+    check(_lib.lib().bpp_points_decompress(arith.handle, _ptr(raw), raw.shape[0], _ptr(pts), _ptr(ok)),
+          "bpp_points_decompress")
+    return pts, ok
+
+
 class PublicKey:
     """reference publickey.rs:13-52.  Fields g, h, G_vec, H_vec as in the reference."""
 
@@ -345,6 +369,17 @@ class BatchVerifier:
         ok = np.zeros(count, dtype=np.uint32)
         check(_lib.lib().bpp_range_verify_batch(self.handle, _ptr(pts), _ptr(sc), count, _ptr(ok)),
               "bpp_range_verify_batch")
+        return ok
+
+    def verify_compressed(self, records, scalars) -> np.ndarray:
+        """records (count, 3+2k+m, compressed_bytes) u8 in the order of verify_wire, scalars (count, 3, 4) -> ok"""
+        cb = compressed_bytes(self.arith)
+        rec = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, self.points_per_proof, cb)
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
+        count = rec.shape[0]
+        ok = np.zeros(count, dtype=np.uint32)
+        check(_lib.lib().bpp_range_verify_batch_compressed(self.handle, _ptr(rec), _ptr(sc), count, _ptr(ok)),
+              "bpp_range_verify_batch_compressed")
         return ok
 
     def run_device(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" boundary of libbpp_amd.so (declared in include/bpp_amd.h).  Thin: argument
 // checks, curve dispatch, then the per-curve implementations (impl_*.hpp, compiled in tu_*.hip).
 // No CPU fallback: every entry point launches HIP kernels on the context's device.
+#include "codec.hpp"
 #include "impl_msm.hpp"
 #include "impl_prove.hpp"
 #include "impl_verify.hpp"
@@ -240,6 +241,70 @@ extern "C" int bpp_range_verify_batch(bpp_verifier* v, const uint64_t* points, c
                               dok.u32(), dws.p, wsb, nullptr, nullptr, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
+    return BPP_OK;
+}
+
+// ---- compressed point encodings (codec.hpp) ---------------------------------------------------------------
+extern "C" size_t bpp_point_compressed_bytes(int curve_id) {
+    switch (curve_id) {
+        case BPP_BLS12_381_G1: return 48;
+        case BPP_SECP256K1: return 33;
+        default: return 0;
+    }
+}
+
+extern "C" int bpp_points_compress(bpp_ctx* ctx, const uint64_t* points, size_t n, uint8_t* out) {
+    if (!ctx || (n && (!points || !out))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int { return CodecImpl<decltype(cv)>::compress(points, n, out); });
+}
+
+extern "C" int bpp_points_decompress(bpp_ctx* ctx, const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
+    if (!ctx || (n && (!in || !out_points || !out_ok))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve,
+                    [&](auto cv) -> int { return CodecImpl<decltype(cv)>::decompress(in, n, out_points, out_ok); });
+}
+
+extern "C" int bpp_points_decompress_device(bpp_ctx* ctx, const void* d_in, size_t n, uint64_t* d_points, uint32_t* d_ok,
+                                            void* stream) {
+    if (!ctx || (n && (!d_in || !d_points || !d_ok))) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return CodecImpl<decltype(cv)>::decompress_device(static_cast<const uint8_t*>(d_in), n, d_points, d_ok,
+                                                          static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t* records, const uint64_t* scalars,
+                                                 size_t count, uint32_t* out_ok) {
+    if (!v || !records || !scalars || !out_ok) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(v->ctx.device));
+    const size_t cb = bpp_point_compressed_bytes(v->ctx.curve);
+    if (cb == 0) return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+    const size_t pw = (size_t)bpp_point_words(v->ctx.curve) * 8;
+    const size_t npts = count * v->s.NV;
+    DevBuf db, dp, dk, ds, dok, dws;
+    HIPCHK(db.alloc(npts * cb));
+    HIPCHK(dp.alloc(npts * pw));
+    HIPCHK(dk.alloc(npts * 4));
+    HIPCHK(ds.alloc(count * 3 * 32));
+    HIPCHK(dok.alloc(count * 4));
+    const size_t wsb = bpp_verifier_workspace_bytes(v, count);
+    HIPCHK(dws.alloc(wsb));
+    HIPCHK(hipMemcpy(db.p, records, npts * cb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ds.p, scalars, count * 3 * 32, hipMemcpyHostToDevice));
+    int rc = bpp_points_decompress_device(&v->ctx, db.p, npts, static_cast<uint64_t*>(dp.p), dk.u32(), nullptr);
+    if (rc) return rc;
+    rc = bpp_verifier_run(v, static_cast<const uint64_t*>(dp.p), static_cast<const uint64_t*>(ds.p), count, nullptr,
+                          dok.u32(), dws.p, wsb, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<uint32_t> bad(npts);
+    HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(bad.data(), dk.p, npts * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < npts; i++)
+        if (bad[i]) out_ok[i / v->s.NV] = 1;   // a malformed encoding rejects its proof (ProofError::FormatError's role)
     return BPP_OK;
 }
 

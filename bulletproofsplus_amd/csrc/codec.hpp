@@ -1,0 +1,230 @@
+// codec.hpp -- standard COMPRESSED point encodings <-> the C ABI's wire points, on the device.
+//
+// A data format next to the hot path.  The reference has no serialization: only the
+// commented-out size() functions (src/range/mod.rs:512-517, src/weighted_inner_product_proof.rs:384-397), which
+// assume compressed points and 32-byte scalars, and the reserved ProofError::FormatError (src/errors.rs:20).
+// So nothing here can be pinned by reference code -- PARITY UNPINNED; it is pinned by the public standard
+// vectors of the encodings (generator encodings) and by oracle/pyref.py's big-integer restatement.
+//
+//   BLS12-381 G1 : 48 bytes, x big-endian; byte 0 bit 7 = compressed (always 1), bit 6 = infinity, bit 5 = y is
+//                  the lexicographically larger root (y > (p-1)/2)           [ZCash / IETF pairing-friendly curves]
+//   secp256k1    : 33 bytes, SEC1: 0x02 (y even) / 0x03 (y odd) || x big-endian; infinity = 33 zero bytes (SEC1's
+//                  one-byte 0x00, padded to the fixed width)
+// Decompression costs one square root per point: both base fields have p = 3 mod 4, so y = (x^3 + b)^((p+1)/4),
+// ~1.2 BITS Montgomery products, checked by squaring.  edwards25519 is not offered (not a reference backend).
+#pragma once
+#include "host_util.hpp"
+
+namespace bpp {
+
+template <class C>
+struct has_codec {
+    static constexpr bool value = C::Fp::SQRT_3MOD4;
+};
+
+template <class C>
+constexpr int compressed_bytes() {
+    return C::ID == 0 ? 48 : 33;
+}
+
+// a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4 (MSB-first square-and-multiply over the
+// public constant P::SQRTW); the caller checks the result by squaring
+template <class P>
+BPP_HD Fe<P> fe_sqrt_3mod4(const Fe<P>& a) {
+    Fe<P> acc = Fe<P>::one();
+    bool started = false;
+    for (int i = P::N * 32 - 1; i >= 0; i--) {
+        if (started) acc = fe_sqr(acc);
+        if ((P::SQRTW[i >> 5] >> (i & 31)) & 1u) {
+            acc = started ? fe_mul(acc, a) : a;
+            started = true;
+        }
+    }
+    return acc;
+}
+
+// canonical words > (p - 1) / 2 ?
+template <class P>
+BPP_HD bool words_gt_half(const uint32_t* w) {
+    for (int i = P::N - 1; i >= 0; i--) {
+        if (w[i] != P::HALFW[i]) return w[i] > P::HALFW[i];
+    }
+    return false;
+}
+
+// one thread per point: wire (canonical x | y | inf) -> compressed bytes
+template <class C>
+__global__ void __launch_bounds__(128) k_points_compress(const uint32_t* __restrict__ wire, uint8_t* __restrict__ out, size_t n) {
+    using P = typename C::Fp;
+    constexpr int N = P::N;
+    constexpr int CB = compressed_bytes<C>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = wire + i * (2 * N + 2);
+    uint8_t* o = out + i * CB;
+    const bool inf = (w[2 * N] | w[2 * N + 1]) != 0;
+    if (C::ID == 0) {
+        // x big-endian over 48 bytes; flags in the three top bits (x < p < 2^381 leaves them free)
+        for (int b = 0; b < 48; b++) {
+            const int k = 47 - b;   // byte k of the little-endian value
+            o[b] = inf ? 0 : (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        }
+        uint8_t flags = 0x80;
+        if (inf) flags |= 0x40;
+        else if (words_gt_half<P>(w + N)) flags |= 0x20;
+        o[0] |= flags;
+    } else {
+        if (inf) {
+            for (int b = 0; b < 33; b++) o[b] = 0;
+        } else {
+            o[0] = (w[N] & 1u) ? 0x03 : 0x02;
+            for (int b = 0; b < 32; b++) {
+                const int k = 31 - b;
+                o[1 + b] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+    }
+}
+
+// one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (bad flags, x >= p, x not on the curve)
+template <class C>
+__global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
+                                                          uint32_t* __restrict__ ok, size_t n) {
+    using P = typename C::Fp;
+    using F = Fe<P>;
+    constexpr int N = P::N;
+    constexpr int CB = compressed_bytes<C>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* s = in + i * CB;
+    uint32_t* w = wire + i * (2 * N + 2);
+    auto fail_point = [&]() {
+        for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
+        w[2 * N] = 1;   // infinity, so that a consumer that ignores ok[] still sees a valid wire point
+        ok[i] = 1;
+    };
+    uint32_t x[N];
+    for (int t = 0; t < N; t++) x[t] = 0;
+    bool inf = false, want_flag = false;
+    if (C::ID == 0) {
+        const uint8_t f = s[0];
+        if (!(f & 0x80)) return fail_point();   // uncompressed form is not accepted here
+        inf = (f & 0x40) != 0;
+        want_flag = (f & 0x20) != 0;
+        for (int b = 0; b < 48; b++) {
+            const int k = 47 - b;
+            const uint32_t v = b == 0 ? (uint32_t)(s[0] & 0x1f) : (uint32_t)s[b];
+            x[k >> 2] |= v << (8 * (k & 3));
+        }
+        if (inf) {
+            bool zero = !want_flag;
+            for (int t = 0; t < N; t++) zero = zero && x[t] == 0;
+            if (!zero) return fail_point();   // infinity must be 0xc0 00 .. 00
+        }
+    } else {
+        const uint8_t f = s[0];
+        bool all_zero = true;
+        for (int b = 0; b < 33; b++) all_zero = all_zero && s[b] == 0;
+        if (all_zero) {
+            inf = true;
+        } else {
+            if (f != 0x02 && f != 0x03) return fail_point();
+            want_flag = f == 0x03;   // y odd
+            for (int b = 0; b < 32; b++) {
+                const int k = 31 - b;
+                x[k >> 2] |= (uint32_t)s[1 + b] << (8 * (k & 3));
+            }
+        }
+    }
+    if (inf) {
+        for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
+        w[2 * N] = 1;
+        ok[i] = 0;
+        return;
+    }
+    if (!words_lt_mod<P>(x)) return fail_point();
+    const F xm = fe_from_canonical<P>(x);
+    F b;
+#pragma unroll
+    for (int t = 0; t < P::NL; t++) b.l[t] = C::K::B[t];
+    const F rhs = fe_add(fe_mul(fe_sqr(xm), xm), b);
+    F y = fe_sqrt_3mod4(rhs);
+    if (fe_sqr(y) != rhs) return fail_point();   // x^3 + b is not a square: no such point
+    uint32_t yw[N];
+    fe_to_canonical(y, yw);
+    const bool flag = C::ID == 0 ? words_gt_half<P>(yw) : (yw[0] & 1u) != 0;
+    if (flag != want_flag) {
+        y = fe_neg(y);
+        fe_to_canonical(y, yw);
+    }
+    // y = 0 cannot carry the "larger" / "odd" flag; it does not occur on these curves (no point of order 2)
+    for (int t = 0; t < N; t++) {
+        w[t] = x[t];
+        w[N + t] = yw[t];
+    }
+    w[2 * N] = 0;
+    w[2 * N + 1] = 0;
+    ok[i] = 0;
+}
+
+template <class C>
+struct CodecImpl {
+    static constexpr int N = C::Fp::N;
+    static constexpr int WW = 2 * N + 2;
+
+    static int compress(const uint64_t* points, size_t n, uint8_t* out) {
+        if constexpr (!has_codec<C>::value) {
+            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+        } else {
+            if (n == 0) return BPP_OK;
+            constexpr int CB = compressed_bytes<C>();
+            DevBuf dw, db;
+            HIPCHK(dw.alloc(n * WW * 4));
+            HIPCHK(db.alloc(n * CB));
+            HIPCHK(hipMemcpy(dw.p, points, n * WW * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_points_compress<C>, dim3(cdiv(n, 128)), dim3(128), 0, nullptr, dw.u32(),
+                               static_cast<uint8_t*>(db.p), n);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpy(out, db.p, n * CB, hipMemcpyDeviceToHost));
+            return BPP_OK;
+        }
+    }
+
+    // device to device: `d_in` n x CB bytes, `d_wire` n wire points, `d_ok` n words
+    static int decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st) {
+        if constexpr (!has_codec<C>::value) {
+            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+        } else {
+            if (n == 0) return BPP_OK;
+            hipLaunchKernelGGL(k_points_decompress<C>, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in,
+                               reinterpret_cast<uint32_t*>(d_wire), d_ok, n);
+            HIPCHK(hipGetLastError());
+            return BPP_OK;
+        }
+    }
+
+    static int decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
+        if constexpr (!has_codec<C>::value) {
+            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+        } else {
+            if (n == 0) return BPP_OK;
+            constexpr int CB = compressed_bytes<C>();
+            DevBuf dw, db, dk;
+            HIPCHK(dw.alloc(n * WW * 4));
+            HIPCHK(db.alloc(n * CB));
+            HIPCHK(dk.alloc(n * 4));
+            HIPCHK(hipMemcpy(db.p, in, n * CB, hipMemcpyHostToDevice));
+            int rc = decompress_device(static_cast<const uint8_t*>(db.p), n, static_cast<uint64_t*>(dw.p), dk.u32(), nullptr);
+            if (rc) return rc;
+            HIPCHK(hipMemcpy(out_points, dw.p, n * WW * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(out_ok, dk.p, n * 4, hipMemcpyDeviceToHost));
+            return BPP_OK;
+        }
+    }
+};
+
+extern template struct CodecImpl<Bls12381>;
+extern template struct CodecImpl<Secp256k1>;
+extern template struct CodecImpl<Ed25519>;
+
+}  // namespace bpp

@@ -1,5 +1,7 @@
 // explicit instantiation: MsmImpl<Secp256k1> (its kernels are compiled in this translation unit only)
+#include "codec.hpp"
 #include "impl_msm.hpp"
 namespace bpp {
 template struct MsmImpl<Secp256k1>;
+template struct CodecImpl<Secp256k1>;
 }

@@ -178,6 +178,26 @@ int bpp_verifier_profile(bpp_verifier *v, float *out_stage_ms, size_t *out_passe
 int bpp_range_verify_batch(bpp_verifier *v, const uint64_t *points, const uint64_t *scalars, size_t count,
                            uint32_t *out_ok);
 
+/* ---- compressed point encodings: a data format next to the path ---------------------------------
+ * The reference has no serialization; its commented-out size() functions (src/range/mod.rs:512-517,
+ * src/weighted_inner_product_proof.rs:384-397) assume compressed points + 32-byte scalars and
+ * src/errors.rs:20 reserves ProofError::FormatError for it.  PARITY UNPINNED by the reference; pinned by the
+ * encodings' public generator vectors and oracle/pyref.py.
+ *   BLS12-381 G1: 48 bytes, x big-endian, byte 0 bit 7 = compressed, bit 6 = infinity, bit 5 = y > (p-1)/2
+ *   secp256k1   : 33 bytes, SEC1 02/03 || x big-endian; infinity = 33 zero bytes
+ * (0 bytes = not offered: edwards25519.)  Decompression runs on the device (one square root per point);
+ * out_ok[i] = 0 valid, 1 malformed (flags, x >= p, x not on the curve) -- such a point is returned as infinity. */
+size_t bpp_point_compressed_bytes(int curve_id);
+int bpp_points_compress(bpp_ctx *ctx, const uint64_t *points, size_t n, uint8_t *out);
+int bpp_points_decompress(bpp_ctx *ctx, const uint8_t *in, size_t n, uint64_t *out_points, uint32_t *out_ok);
+/* device buffers, asynchronous on `stream`: feeds bpp_verifier_run's d_points without touching the host */
+int bpp_points_decompress_device(bpp_ctx *ctx, const void *d_in, size_t n, uint64_t *d_points, uint32_t *d_ok,
+                                 void *stream);
+/* bpp_range_verify_batch over serialized proofs: records = count x (3 + 2k + m) compressed points in the order
+ * of d_points above, scalars = count x 3 (4 x u64 each).  A malformed point rejects its proof. */
+int bpp_range_verify_batch_compressed(bpp_verifier *v, const uint8_t *records, const uint64_t *scalars, size_t count,
+                                      uint32_t *out_ok);
+
 /* name of the kernel that dominates bpp_verifier_run (for profilers) and its launch geometry */
 const char *bpp_verifier_dominant_kernel(void);
 

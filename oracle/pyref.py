@@ -797,6 +797,61 @@ class RangeProof:
 # Convenience
 # --------------------------------------------------------------------------------------
 
+# ---- compressed point encodings (TEST ORACLE for csrc/codec.hpp; no reference counterpart: the reference has no
+# serialization, only the commented-out size() fns of range/mod.rs:512-517 and wip.rs:384-397) ------------------
+# BLS12-381 G1: 48 bytes, x big-endian, byte 0 bit 7 = compressed, bit 6 = infinity, bit 5 = y > (p-1)/2
+# secp256k1   : SEC1, 33 bytes, 02/03 || x big-endian; infinity = 33 zero bytes (fixed-width variant)
+def compress_point(curve: dict, P) -> bytes:
+    p = curve["p"]
+    if curve["name"] == "bls12_381":
+        if P is None:
+            return bytes([0xC0]) + bytes(47)
+        x, y = P
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if y > (p - 1) // 2 else 0)
+        return bytes(b)
+    if curve["name"] == "secp256k1":
+        if P is None:
+            return bytes(33)
+        x, y = P
+        return bytes([2 + (y & 1)]) + x.to_bytes(32, "big")
+    raise ValueError("no compressed encoding for " + curve["name"])
+
+
+def decompress_point(curve: dict, data: bytes):
+    """-> (ok, point): ok False for a malformed encoding (flags, x >= p, x not on the curve)"""
+    p, b = curve["p"], curve["b"]
+    if curve["name"] == "bls12_381":
+        assert len(data) == 48
+        f = data[0]
+        if not f & 0x80:
+            return False, None
+        x = int.from_bytes(bytes([f & 0x1F]) + data[1:], "big")
+        if f & 0x40:
+            return (x == 0 and not f & 0x20), None
+        want = bool(f & 0x20)
+    elif curve["name"] == "secp256k1":
+        assert len(data) == 33
+        if data == bytes(33):
+            return True, None
+        if data[0] not in (2, 3):
+            return False, None
+        x = int.from_bytes(data[1:], "big")
+        want = data[0] == 3
+    else:
+        raise ValueError("no compressed encoding for " + curve["name"])
+    if x >= p:
+        return False, None
+    rhs = (x * x * x + b) % p
+    y = pow(rhs, (p + 1) // 4, p)      # p = 3 mod 4 for both fields
+    if y * y % p != rhs:
+        return False, None
+    flag = (y > (p - 1) // 2) if curve["name"] == "bls12_381" else bool(y & 1)
+    if flag != want:
+        y = p - y
+    return True, (x, y)
+
+
 def make_group(curve_name: str, shadow: bool):
     c = CURVES[curve_name]
     if shadow:

@@ -1,0 +1,134 @@
+"""Compressed point encodings (csrc/codec.hpp): a data format next to the hot path.
+
+PARITY UNPINNED by the reference -- it has no serialization at all (only the commented-out size() functions,
+range/mod.rs:512-517 and wip.rs:384-397).  What pins the format: the public standard encodings of the two
+generators (ZCash / IETF BLS12-381 G1, SEC1 secp256k1), checked against the big-integer restatement in
+oracle/pyref.py on the CPU; the device kernels are then checked against that restatement."""
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pyref as P
+from gpu_util import need_gpu
+
+# public constants of the encodings
+BLS_G1_COMPRESSED = bytes.fromhex(
+    "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+SECP_G_COMPRESSED = bytes.fromhex("0279be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798")
+CURVES = {"bls12_381": P.BLS12_381, "secp256k1": P.SECP256K1}
+
+
+def _mul(curve, k):
+    return P.WeierstrassGroup(curve).mul(P.WeierstrassGroup(curve).base(), k)
+
+
+def test_oracle_codec_matches_the_standard_generator_encodings():
+    assert P.compress_point(P.BLS12_381, (P.BLS12_381["gx"], P.BLS12_381["gy"])) == BLS_G1_COMPRESSED
+    assert P.compress_point(P.SECP256K1, (P.SECP256K1["gx"], P.SECP256K1["gy"])) == SECP_G_COMPRESSED
+    assert P.decompress_point(P.BLS12_381, BLS_G1_COMPRESSED) == (True, (P.BLS12_381["gx"], P.BLS12_381["gy"]))
+    assert P.decompress_point(P.SECP256K1, SECP_G_COMPRESSED) == (True, (P.SECP256K1["gx"], P.SECP256K1["gy"]))
+    # the other root carries the other flag
+    neg = bytearray(BLS_G1_COMPRESSED); neg[0] |= 0x20
+    assert P.decompress_point(P.BLS12_381, bytes(neg)) == (True, (P.BLS12_381["gx"], P.BLS12_381["p"] - P.BLS12_381["gy"]))
+    assert P.decompress_point(P.SECP256K1, b"\x03" + SECP_G_COMPRESSED[1:])[1][1] == P.SECP256K1["p"] - P.SECP256K1["gy"]
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1"])
+def test_oracle_codec_round_trip_and_rejections(cname):
+    curve = CURVES[cname]
+    G = P.WeierstrassGroup(curve)
+    pts = [None] + [G.mul(G.base(), k) for k in (1, 2, 3, 7, 2**64 + 5, curve["r"] - 1)]
+    for Q in pts:
+        enc = P.compress_point(curve, Q)
+        assert P.decompress_point(curve, enc) == (True, Q)
+    n = 48 if cname == "bls12_381" else 33
+    bad = []
+    if cname == "bls12_381":
+        bad.append(bytes(48))                                              # compression bit missing
+        bad.append(bytes([0xE0]) + bytes(47))                              # infinity with the sign flag
+        bad.append(bytes([0xC0]) + bytes(46) + b"\x01")                    # infinity with a non-zero x
+        bad.append(bytes([0x80 | 0x1A]) + b"\xff" * 47)                    # x >= p
+    else:
+        bad.append(b"\x04" + bytes(32))                                    # unknown prefix
+        bad.append(b"\x02" + b"\xff" * 32)                                 # x >= p
+    # an x that is not on the curve
+    x = 5
+    while pow((x ** 3 + curve["b"]) % curve["p"], (curve["p"] - 1) // 2, curve["p"]) == 1:
+        x += 1
+    bad.append((bytes([0x80]) + x.to_bytes(48, "big")[1:]) if cname == "bls12_381" else b"\x02" + x.to_bytes(32, "big"))
+    for enc in bad:
+        assert len(enc) == n and P.decompress_point(curve, enc)[0] is False, enc.hex()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1"])
+def test_device_codec_matches_oracle(cname):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    curve, cid = CURVES[cname], O.CURVE_IDS[cname]
+    a = B.Arith.init(cname)
+    G = P.WeierstrassGroup(curve)
+    rnd = np.random.RandomState(11)
+    ks = [1, 2, 3, curve["r"] - 1] + [int.from_bytes(rnd.bytes(32), "little") % curve["r"] or 1 for _ in range(300)]
+    pts = [None] + [G.mul(G.base(), k) for k in ks]
+    wire = O.points_to_wire(cid, pts)
+    enc = B.compress_points(a, wire)
+    assert enc.shape == (len(pts), B.compressed_bytes(a))
+    exp = [P.compress_point(curve, Q) for Q in pts]
+    assert [bytes(r) for r in enc] == exp
+    assert bytes(enc[1]) == (BLS_G1_COMPRESSED if cname == "bls12_381" else SECP_G_COMPRESSED)
+    back, ok = B.decompress_points(a, enc)
+    assert ok.tolist() == [0] * len(pts) and np.array_equal(back, wire)
+    # flipping the root flag gives the negative point
+    flip = enc.copy()
+    if cname == "bls12_381":
+        flip[1:, 0] ^= 0x20
+    else:
+        flip[1:, 0] ^= 0x01
+    back2, ok2 = B.decompress_points(a, flip)
+    assert ok2.tolist() == [0] * len(pts)
+    assert O.wire_to_points(cid, back2)[1:] == [(x, curve["p"] - y) for (x, y) in pts[1:]]
+    # malformed encodings: the same verdicts as the oracle, and the point comes back as infinity
+    bad = []
+    for r in enc[1:40]:
+        b = bytearray(bytes(r))
+        b[-1] ^= 1                                                          # x moved: about half are off the curve
+        bad.append(bytes(b))
+    if cname == "bls12_381":
+        bad += [bytes(48), bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\x01", bytes([0x9A]) + b"\xff" * 47]
+    else:
+        bad += [b"\x04" + bytes(32), b"\x02" + b"\xff" * 32, b"\x00" + b"\x01" * 32]
+    raw = np.frombuffer(b"".join(bad), dtype=np.uint8).reshape(len(bad), -1)
+    got, okb = B.decompress_points(a, raw)
+    exp_ok = [P.decompress_point(curve, e) for e in bad]
+    assert okb.tolist() == [0 if v else 1 for v, _ in exp_ok]
+    assert 0 < sum(okb.tolist()) < len(bad)
+    assert O.wire_to_points(cid, got) == [Q if v else None for v, Q in exp_ok]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1"])
+def test_verify_serialized_proofs(cname):
+    """bpp_range_verify_batch_compressed == the wire-format verdicts; a malformed point rejects its proof only."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init(cname)
+    n, m = 8, 2
+    pk = B.PublicKey.new(a, n * m)
+    eng = B.BatchVerifier(pk, n, m, window_bits=6)
+    vals = [[3, 200], [255, 0], [17, 99], [1, 2]]
+    gams = [[5, 6], [7, 8], [9, 10], [11, 12]]
+    pts, sc, V = eng.prove_batch(vals, gams)
+    recs = np.concatenate([pts, V], axis=1)
+    bad_sc = sc.copy()
+    bad_sc[1, 0, 0] ^= 1
+    exp = eng.verify_wire(recs, bad_sc).tolist()
+    assert exp == [0, 1, 0, 0]
+    enc = B.compress_points(a, recs.reshape(-1, a.PW)).reshape(len(vals), eng.points_per_proof, -1)
+    assert eng.verify_compressed(enc, bad_sc).tolist() == exp
+    # proof 2 carries a malformed L_0 (unknown prefix / missing compression bit); proof 3 carries -A instead of A
+    enc2 = enc.copy()
+    enc2[2, 3, 0] = 0x04 if cname == "secp256k1" else 0x00
+    enc2[3, 0, 0] ^= 0x01 if cname == "secp256k1" else 0x20
+    assert eng.verify_compressed(enc2, bad_sc).tolist() == [0, 1, 1, 1]
