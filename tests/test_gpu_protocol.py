@@ -314,6 +314,44 @@ def test_prove_batch_matches_oracle_small(cname, n, m, c):
     assert exp_ok[0] == 0 and exp_ok[3] == 1
 
 
+@pytest.mark.parametrize("cname,n,m,c,count", [
+    ("bls12_381", 2, 2, 3, 1),        # NF = 10: fewer generators than lanes
+    ("bls12_381", 4, 8, 7, 70),       # NF = 66
+    ("secp256k1", 16, 2, 9, 300),     # NF = 66, 256-bit scalars
+    ("bls12_381", 16, 8, 4, 33),      # NF = 258 = 2 * 128 + 2: whole generators + left-over ones, 64 windows
+    ("bls12_381", 32, 8, 11, 2500),   # NF = 514, one block per proof: 4 generators per lane + 2 spread
+    ("ed25519", 8, 4, 6, 40),         # extended Edwards coordinates through the same kernels
+])
+def test_shapes_and_batch_sizes_sweep(cname, n, m, c, count):
+    """Launch geometry sweep of k_fixed_msm (lanes without generators, whole + left-over generators, one or several
+    blocks per proof, fold passes): verdicts for valid / tampered proofs, and the MulVec result point of a few of
+    them against the oracle."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    a = B.Arith.init(cname)
+    pk = B.PublicKey.new(a, n * m)
+    eng = B.BatchVerifier(pk, n, m, window_bits=c)
+    rnd = np.random.RandomState(n * 1000 + m * 10 + c)
+    vals = rnd.randint(0, min(2**31 - 1, 2**n), size=(count, m)).astype(np.uint64)
+    gams = [[int(x) for x in row] for row in rnd.randint(1, 2**62, size=(count, m))]
+    pts, sc, V = eng.prove_batch(vals, gams)
+    recs = np.concatenate([pts, V], axis=1)
+    bad = sorted(set(rnd.choice(count, size=max(1, count // 7), replace=False).tolist()))
+    dsc = sc.copy()
+    for t, i in enumerate(bad):
+        dsc[i, t % 3, rnd.randint(4)] ^= np.uint64(1) << np.uint64(rnd.randint(60))
+    ok, _, res = run_verifier_device(torch, eng, recs, dsc, want_scalars=False)
+    assert ok.tolist() == [1 if i in bad else 0 for i in range(count)]
+    assert all(a.is_zero(res[i]) for i in range(count) if i not in bad)
+    if cname != "ed25519":   # the C oracle has no Edwards backend
+        cid = CID[cname]
+        opk = O.PublicKey(cid, n * m)
+        for i in ([0] + bad)[:3]:
+            rc, _, exp = O.range_verify(opk, n, m, pts[i], dsc[i], V[i], want_result=True)
+            assert rc == (1 if i in bad else 0) and np.array_equal(res[i], exp), i
+    eng.close()
+
+
 def test_prove_batch_reference_sizes(golden):
     """(64,2) main.rs, (32,1) and (64,16): batched prover == golden proofs; a distinct batch verifies."""
     need_gpu()
