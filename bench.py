@@ -15,7 +15,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                    on the launch stream inside the timed region, algorithmic bytes per DESIGN.md;
   "cpu_baseline" : the CPU oracle (oracle/bpp_oracle.c, kind "port" -- the reference itself is Rust +
                    the absent mcl_rust and cannot be built) timed on a bounded sample on this host.
-The oracle is used only for that leg.
+The oracle is used only for that leg.  Beside `value` (never as it) the line also carries separately timed legs:
+"combined_check" (random-linear-combination batch check), "hard_distribution" (random generators, per-proof random
+full-width challenges: SURVEY.md 8d) and "other_curves" (the same shape on the edwards25519 and secp256k1
+instantiations of the same kernels).
 """
 
 import argparse
@@ -93,6 +96,9 @@ def main():
     ap.add_argument("--cpu-per-thread", type=int, default=2)
     ap.add_argument("--combined-steps", type=int, default=-1,
                     help="extra (separately timed) steps of the combined batch check; -1 = same as --steps, 0 = skip")
+    ap.add_argument("--other-curves-steps", type=int, default=3,
+                    help="steps per extra leg on the other two instantiations of the same kernels (edwards25519 -- the curve "
+                         "under Ristretto255, which BASELINE.json's configs[1] names -- and secp256k1); 0 = skip")
     ap.add_argument("--hard-steps", type=int, default=4,
                     help="steps of the 'hard distribution' leg (random generators, random full-width challenges; SURVEY 8d); 0 = skip")
     args = ap.parse_args()
@@ -315,6 +321,62 @@ def main():
                         "challenges, so they are rejected here -- the pass does the same work for valid and invalid proofs"}
         bv_h.close()
 
+    # ---- secondary, separately timed: the same shape on the other instantiations of the same kernel templates.
+    # BASELINE.json's configs[1] names Ristretto; the reference has no such backend, so the
+    # edwards25519 instantiation is parity-unpinned and can never be the headline; secp256k1 is the reference's
+    # second in-tree backend.  Window 16 for both (65 / 73 GB of tables).
+    others = None
+    if args.other_curves_steps > 0 and args.curve == "bls12_381":
+        others = {}
+        if bv.handle:
+            bv.close()
+        try:
+            del d_ws
+        except NameError:   # the hard-distribution leg has released it already
+            pass
+        torch.cuda.empty_cache()
+        for oc in ("ed25519", "secp256k1"):
+            a_o = B.Arith.init(oc, local_rank)
+            pk_o = B.PublicKey.new(a_o, n * m)
+            bv_o = B.BatchVerifier(pk_o, n, m, window_bits=16)
+            pts_o, scs_o, V_o = bv_o.prove_batch(vals, gams)
+            recs_o = np.ascontiguousarray(np.concatenate([pts_o, V_o], axis=1))
+            scs_o = np.ascontiguousarray(scs_o)
+            if D < Bsz:
+                recs_o = np.ascontiguousarray(recs_o[np.arange(Bsz) % D])
+                scs_o = np.ascontiguousarray(scs_o[np.arange(Bsz) % D])
+            d_pts_o = torch.from_numpy(recs_o.view(np.int64)).to(dev)
+            d_sc_o = torch.from_numpy(scs_o.view(np.int64)).to(dev)
+            wsb_o = bv_o.workspace_bytes(Bsz)
+            d_ws_o = torch.empty(wsb_o, dtype=torch.uint8, device=dev)
+            bv_o.run_device(d_pts_o.data_ptr(), d_sc_o.data_ptr(), Bsz, d_ok.data_ptr(), d_ws_o.data_ptr(), wsb_o, stream)
+            torch.cuda.synchronize()
+            assert int(d_ok.sum().item()) == 0, "%s: a valid proof failed to verify" % oc
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            to0 = time.perf_counter()
+            for _ in range(args.other_curves_steps):
+                bv_o.run_device(d_pts_o.data_ptr(), d_sc_o.data_ptr(), Bsz, d_ok.data_ptr(), d_ws_o.data_ptr(), wsb_o,
+                                stream)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            odt = time.perf_counter() - to0
+            if dist is not None:
+                tmax = torch.tensor([odt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                odt = float(tmax.item())
+            others[oc] = {"value": world * Bsz * args.other_curves_steps / odt, "unit": "verifies/s",
+                          "steps": args.other_curves_steps, "ms_per_step": odt / args.other_curves_steps * 1e3,
+                          "window_bits": 16, "table_bytes": bv_o.table_bytes,
+                          "parity": ("unpinned: not a reference backend; the prime-order subgroup of the curve under Ristretto255"
+                                     if oc == "ed25519" else "the reference's second in-tree backend (not wired to its range proof)")}
+            bv_o.close()
+            del d_ws_o, d_pts_o, d_sc_o
+            torch.cuda.empty_cache()
+
     if rank == 0:
         N_msm = msm_len_main
         NF = 2 * n * m + 2
@@ -366,6 +428,7 @@ def main():
             "stage_ms": stage_ms,
             "combined_check": comb,
             "hard_distribution": hard,
+            "other_curves": others,
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},
         }
         thr = args.cpu_threads
