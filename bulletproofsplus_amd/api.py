@@ -257,6 +257,22 @@ class RangeProver:
         self.commitment_vec.append(out)
 
 
+class RangeVerifier:
+    """The verifier-side holder of the commitments.  It exists only in the reference's (stale) README
+    (README.md:47-55: ``RangeVerifier::new()``, ``allocate(&prover.commitment_vec)``, ``proof.verify(.., &verifier)``);
+    the code takes the commitment slice directly (range/mod.rs:57-62).  ``RangeProof.verify`` accepts either."""
+
+    def __init__(self):
+        self.commitment_vec = []
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def allocate(self, commitment_vec):
+        self.commitment_vec = [np.ascontiguousarray(c, dtype=np.uint64) for c in commitment_vec]
+
+
 class WeightedInnerProductProof:
     """Field holder, reference weighted_inner_product_proof.rs:25-33."""
 
@@ -313,6 +329,8 @@ class RangeProof:
     def verify(self, pk: PublicKey, n: int, commitment_vec) -> None:
         """Returns None for Ok(()); raises VerificationError for Err(ProofError::VerificationError)."""
         a = pk.arith
+        if isinstance(commitment_vec, RangeVerifier):   # the README's calling convention
+            commitment_vec = commitment_vec.commitment_vec
         V = np.ascontiguousarray(np.asarray(commitment_vec, dtype=np.uint64).reshape(-1, a.PW))
         m = V.shape[0]
         pts = np.ascontiguousarray(self.points_wire())

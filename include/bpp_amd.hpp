@@ -9,6 +9,7 @@
 //   bpp::MulVec                                bls12_381/building_block/mulvec.rs:7-53
 //   bpp::PublicKey{g,h,G_vec,H_vec}            publickey.rs:13-52
 //   bpp::RangeProver{v_vec,gamma_vec,commitment_vec}   range/prover.rs:13-42
+//   bpp::RangeVerifier{commitment_vec}.allocate()       README.md:47-48 (no code in the reference)
 //   bpp::WeightedInnerProductProof             weighted_inner_product_proof.rs:25-33
 //   bpp::RangeProof{A, proof}::prove / verify  range/mod.rs:25-78
 //   bpp::ProofError::VerificationError         errors.rs:14-50
@@ -161,6 +162,14 @@ struct RangeProver {
     }
 };
 
+// Verifier-side holder of the commitments.  It exists only in the reference's (stale) README
+// (README.md:47-55: RangeVerifier::new(), allocate(&prover.commitment_vec), proof.verify(.., &verifier));
+// the reference's code takes the commitment slice directly (range/mod.rs:57-62).  Both forms are offered.
+struct RangeVerifier {
+    std::vector<Point> commitment_vec;
+    void allocate(const std::vector<Point>& commitments) { commitment_vec = commitments; }
+};
+
 struct WeightedInnerProductProof {
     std::vector<Point> L_vec, R_vec;
     Point A, B;
@@ -218,6 +227,9 @@ struct RangeProof {
         if (rc == BPP_OK) return std::nullopt;
         if (rc == BPP_VERIFICATION_ERROR) return ProofError::VerificationError;
         throw std::runtime_error(std::string("bpp_range_verify: ") + bpp_last_error());
+    }
+    std::optional<ProofError> verify(const PublicKey& pk, size_t n, const RangeVerifier& verifier) const {
+        return verify(pk, n, verifier.commitment_vec);
     }
 };
 

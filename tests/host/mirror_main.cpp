@@ -25,7 +25,9 @@ int main() {
     printf("verify=%s\n", result ? "Err(VerificationError)" : "Ok(())");
     RangeProof bad = proof;
     bad.proof.d_prime.e[0] ^= 1;
-    auto r2 = bad.verify(pk, n, prover.commitment_vec);
+    RangeVerifier verifier;                        // the README's calling convention (README.md:47-55)
+    verifier.allocate(prover.commitment_vec);
+    auto r2 = bad.verify(pk, n, verifier);
     printf("tampered=%s\n", r2 ? "Err(VerificationError)" : "Ok(())");
     // MulVec panics on a length mismatch (mulvec.rs:23-25)
     MulVec mv;

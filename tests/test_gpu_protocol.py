@@ -67,6 +67,12 @@ def test_prove_and_verify_reference_sizes(golden):
         bad.proof.d_prime[0] ^= 1
         with pytest.raises(B.VerificationError):
             bad.verify(pk, n, pr.commitment_vec)
+        # the README's calling convention (README.md:47-55): RangeVerifier::new(), allocate(..), verify(.., &verifier)
+        rv = B.RangeVerifier.new()
+        rv.allocate(pr.commitment_vec)
+        assert proof.verify(pk, n, rv) is None
+        with pytest.raises(B.VerificationError):
+            bad.verify(pk, n, rv)
         # wrong commitment
         V2 = np.stack(pr.commitment_vec).copy()
         V2[0] = pk.gh[0]
