@@ -192,7 +192,7 @@ struct VerifyImpl {
         uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
         const size_t vlanes = count * VAR_WINDOWS;
         HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
-        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts);
+        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
         hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                            reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
         hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
@@ -232,15 +232,14 @@ struct VerifyImpl {
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
-        size_t pts, bad, scalars, weights, comb_sc, fpart, var_sc, pip, total;
-        PipShape ps;
+        size_t pts, bad, scalars, weights, comb_sc, fpart, var_sc, vdig, vtbl, vscr, vwsum, vfold, total;
         unsigned fixed_blocks;
     };
+    static constexpr uint32_t COMB_FOLD_GROUP = 4;    // proofs whose window sums one lane of k_comb_window_fold adds
     static CombLayout comb_layout(const VerifyShape& s, size_t count) {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         CombLayout w;
         const size_t items = count * s.NV;
-        w.ps = pip_shape(items, pip_pick_c(items));
         w.fixed_blocks = blocks_per_proof(s, 1);
         size_t o = 0;
         w.pts = o;
@@ -254,11 +253,19 @@ struct VerifyImpl {
         w.comb_sc = o;
         o += al((size_t)s.N * 32);
         w.fpart = o;
-        o += al((size_t)w.fixed_blocks * JW * 4);
+        o += al((size_t)(w.fixed_blocks + 1) * JW * 4);            // fixed-generator block sums + the Horner result
         w.var_sc = o;
         o += al(items * 32);
-        w.pip = o;
-        o += al(pip_workspace<C>(w.ps).total);
+        w.vdig = o;
+        o += al(items * VAR_DIGIT_STRIDE);
+        w.vtbl = o;
+        o += al(items * VAR_MULTIPLES * 2 * N * 4);
+        w.vscr = o;
+        o += al(items * 2 * (VAR_MULTIPLES - 1) * N * 4);
+        w.vwsum = o;
+        o += al(count * VAR_WINDOWS * JW * 4);
+        w.vfold = o;
+        o += al((size_t)cdiv(count, COMB_FOLD_GROUP) * VAR_WINDOWS * JW * 4);
         w.total = o;
         return w;
     }
@@ -279,6 +286,11 @@ struct VerifyImpl {
         uint32_t* w_cs = reinterpret_cast<uint32_t*>(ws + L.comb_sc);
         uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
         uint32_t* w_vs = reinterpret_cast<uint32_t*>(ws + L.var_sc);
+        uint8_t* w_vd = ws + L.vdig;
+        uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
+        uint32_t* w_vscr = reinterpret_cast<uint32_t*>(ws + L.vscr);
+        uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
+        uint32_t* w_vf = reinterpret_cast<uint32_t*>(ws + L.vfold);
         const size_t items = count * s.NV;
         HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
         HIPCHK(hipMemsetAsync(w_cs, 0, (size_t)s.N * 32, st));
@@ -290,11 +302,27 @@ struct VerifyImpl {
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
         hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                           w_cs, v->table.u32(), w_fp, L.fixed_blocks, 0u, (const uint32_t*)nullptr,
-                           (uint32_t*)nullptr, (size_t)0);
+        // proof-carried points: weighted scalars -> per-proof Straus window sums -> summed across proofs per window
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
-        HIPCHK(pip_launch<C>(L.ps, w_vs, w_pts, ws + L.pip, w_fp, L.fixed_blocks, d_out_partial, st));
+        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
+        const size_t vlanes = count * VAR_WINDOWS;
+        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
+                           vlanes);
+        uint32_t* cur = w_vw;
+        uint32_t* nxt = w_vf;
+        for (size_t nrem = count; nrem > 1;) {
+            const size_t groups = cdiv(nrem, COMB_FOLD_GROUP);
+            hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * VAR_WINDOWS, 64)), dim3(64), 0, st, cur, nrem,
+                               COMB_FOLD_GROUP, nxt, groups * VAR_WINDOWS);
+            std::swap(cur, nxt);
+            nrem = groups;
+        }
+        // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
+        // leading block; the Horner result lands behind the block sums
+        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
+                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1);
+        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, d_ok, d_out_partial);
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
         HIPCHK(hipGetLastError());
         return BPP_OK;

@@ -904,15 +904,17 @@ __global__ void __launch_bounds__(64) k_partials_fold(const uint32_t* __restrict
 //   var_horner_lane  one lane per proof: Horner over the 65 window sums (4 doublings per step), run by the
 //                  leading blocks of k_fixed_msm's grid
 
+// flat = 0: `scalars` is the verifier's [proof][N] array (the item's scalar sits at var_term_index);
+// flat = 1: `scalars` holds one scalar per item (the combined check's w_p * s_{p,v})
 template <class C>
 __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_t* __restrict__ scalars,
-                                                    uint8_t* __restrict__ digits, size_t items) {
+                                                    uint8_t* __restrict__ digits, size_t items, uint32_t flat) {
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= items) return;
     const size_t b = item / s.NV;
     const uint32_t v = (uint32_t)(item % s.NV);
     uint32_t w[9];
-    ld_words<8>(scalars + (b * s.N + var_term_index(s, v)) * 8, w);
+    ld_words<8>(scalars + (flat ? item : b * s.N + var_term_index(s, v)) * 8, w);
     w[8] = 0;
     uint32_t carry = 0;
 #pragma unroll
