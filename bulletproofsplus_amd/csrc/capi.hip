@@ -305,6 +305,23 @@ extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t*
     HIPCHK(hipMemcpy(bad.data(), dk.p, npts * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < npts; i++)
         if (bad[i]) out_ok[i / v->s.NV] = 1;   // a malformed encoding rejects its proof (ProofError::FormatError's role)
+    // ... and so does a non-canonical scalar (r', s' or delta' >= the group order): a serialized proof has one encoding
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        using Fr = typename decltype(cv)::Fr;
+        for (size_t i = 0; i < count * 3; i++) {
+            const uint64_t* x = scalars + i * 4;
+            bool lt = false;
+            for (int t = 3; t >= 0; t--) {
+                const uint64_t mw = ((uint64_t)Fr::MODW[2 * t + 1] << 32) | Fr::MODW[2 * t];
+                if (x[t] != mw) {
+                    lt = x[t] < mw;
+                    break;
+                }
+            }
+            if (!lt) out_ok[i / 3] = 1;
+        }
+        return BPP_OK;
+    });
     return BPP_OK;
 }
 

@@ -194,7 +194,8 @@ int bpp_points_decompress(bpp_ctx *ctx, const uint8_t *in, size_t n, uint64_t *o
 int bpp_points_decompress_device(bpp_ctx *ctx, const void *d_in, size_t n, uint64_t *d_points, uint32_t *d_ok,
                                  void *stream);
 /* bpp_range_verify_batch over serialized proofs: records = count x (3 + 2k + m) compressed points in the order
- * of d_points above, scalars = count x 3 (4 x u64 each).  A malformed point rejects its proof. */
+ * of d_points above, scalars = count x 3 (4 x u64 each).  A malformed point or a scalar >= the group order
+ * rejects its proof. */
 int bpp_range_verify_batch_compressed(bpp_verifier *v, const uint8_t *records, const uint64_t *scalars, size_t count,
                                       uint32_t *out_ok);
 

@@ -132,3 +132,11 @@ def test_verify_serialized_proofs(cname):
     enc2[2, 3, 0] = 0x04 if cname == "secp256k1" else 0x00
     enc2[3, 0, 0] ^= 0x01 if cname == "secp256k1" else 0x20
     assert eng.verify_compressed(enc2, bad_sc).tolist() == [0, 1, 1, 1]
+    # a non-canonical scalar (s' + r, the same residue) is a second encoding of the same proof: rejected here,
+    # while the wire-format entry point reduces it and accepts
+    r = CURVES[cname]["r"]
+    nc = sc.copy()
+    nc[0, 1] = O.int_to_limbs(O.limbs_to_int(sc[0, 1]) + r, 4) if O.limbs_to_int(sc[0, 1]) + r < 2**256 else nc[0, 1]
+    if not np.array_equal(nc, sc):
+        assert eng.verify_compressed(enc, nc).tolist() == [1, 0, 0, 0]
+        assert eng.verify_wire(recs, nc).tolist() == [0, 0, 0, 0]
