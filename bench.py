@@ -392,12 +392,18 @@ def main():
         windows = (fr_bits - 1) // args.window + 1
         adds = Bsz * NF * windows
         add_rate = adds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        add_peak = None
+        add_peak = mad_peak = None
         try:
             uj = json.load(open(os.path.join(ROOT, "profiles", "ubench_r01_final.json")))
             add_peak = uj[{"bls12_381": "xyzz_madd_bls", "secp256k1": "xyzz_madd_secp"}[args.curve]]["Gops"]
+            mad_peak = uj["v_mad_u64_u32"]["Gops"] / 1e3          # T lane-ops/s, issue-rate micro-benchmark
         except Exception:
-            add_peak = None
+            add_peak = mad_peak = None
+        # multiplier work of one XYZZ mixed addition (8M + 2S, Y3 with one shared reduction) in v_mad_u64_u32 lane-ops:
+        # NL^2 per product, NL(NL+1)/2 per squaring, NL^2 per Montgomery reduction (9 of them); NL = 13 / 9 limbs
+        nl = 13 if args.curve == "bls12_381" else 9
+        mads_per_add = 8 * nl * nl + 2 * (nl * (nl + 1) // 2) + 9 * nl * nl
+        mad_rate = add_rate * mads_per_add / 1e3                   # T v_mad_u64_u32 lane-ops/s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_fixed_msm.json")
         if os.path.exists(pmc):
@@ -423,6 +429,10 @@ def main():
                          "alu": {"unit": "G mixed additions/s", "achieved": add_rate, "peak": add_peak,
                                  "frac": (add_rate / add_peak) if add_peak else None,
                                  "additions_per_launch": adds,
+                                 "field_products_per_s": add_rate * 10e9,
+                                 "v_mad_u64_u32": {"unit": "T lane-ops/s", "achieved": mad_rate, "peak": mad_peak,
+                                                   "frac": (mad_rate / mad_peak) if mad_peak else None,
+                                                   "per_addition": mads_per_add},
                                  "peak_source": "register-resident XYZZ mixed-addition loop, tools/ubench.hip (profiles/ubench_r01_final.json)"},
                          "note": "integer-ALU bound, not HBM bound (DESIGN.md section 4): `alu` is the meaningful ceiling"},
             "stage_ms": stage_ms,
