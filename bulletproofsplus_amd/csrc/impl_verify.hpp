@@ -49,6 +49,10 @@ constexpr unsigned fixed_lds() {
     return std::max<unsigned>(fixed_lds_bytes<C>(), FIXED_BLOCK * jac_words<C>() * 4);
 }
 
+// The wave-per-proof (tree) Horner is used for a single chain only: a lone proof, and the one Horner of the combined
+// check.  With more tree waves the dispatcher packs them onto shared SIMDs and every chain slows down again
+// (2 proofs: 5.8 ms against 4.3 ms for one; 16 proofs: 6.7 ms against 5.7 ms with one lane per proof).
+constexpr size_t HORNER_TREE_MAX = 1;
 constexpr unsigned FOLD_GROUP = 8;    // thread partials summed by one lane of k_partials_fold (first pass)
 constexpr unsigned FOLD_GROUP2 = 4;   // ... and of the second pass
 
@@ -199,10 +203,12 @@ struct VerifyImpl {
                            vlanes);
         HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-        const unsigned hb = cdiv(count, FIXED_BLOCK);
+        // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree)
+        const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
+        const unsigned hb = tree ? cdiv(count, FIXED_BLOCK / 64) : cdiv(count, FIXED_BLOCK);
         uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count);
+                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree);
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
         // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
@@ -321,7 +327,7 @@ struct VerifyImpl {
         // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
         // leading block; the Horner result lands behind the block sums
         hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
-                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1);
+                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u);
         hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, d_ok, d_out_partial);
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
         HIPCHK(hipGetLastError());
@@ -375,7 +381,7 @@ struct VerifyImpl {
                                d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
             hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
                                fixed_lds<C>(), st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per, 0u,
-                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0);
+                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0, 0u);
             hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
                                d_pts.u32(), d_V.u32(), nv_total);
             HIPCHK(hipGetLastError());
