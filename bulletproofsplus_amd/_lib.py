@@ -27,6 +27,7 @@ VERIFICATION_ERROR = 1
 EXPORTS = [
     "bpp_init", "bpp_destroy", "bpp_last_error", "bpp_point_words", "bpp_msm", "bpp_msm_batch", "bpp_msm_pippenger",
     "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_commit", "bpp_range_prove", "bpp_range_prove_batch", "bpp_range_verify",
+    "bpp_prover_workspace_bytes", "bpp_range_prove_batch_device",
     "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
     "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
     "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_partial_bytes",
@@ -70,6 +71,9 @@ def lib():
         L.bpp_range_prove.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
         L.bpp_range_verify.argtypes = [vp, vp, vp, vp, sz, sz, vp, sz, vp, vp]
         L.bpp_range_prove_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+        L.bpp_prover_workspace_bytes.argtypes = [vp, sz]
+        L.bpp_prover_workspace_bytes.restype = sz
+        L.bpp_range_prove_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, sz, vp]
         L.bpp_verifier_create.argtypes = [vp, vp, vp, vp, sz, sz, i32, ctypes.POINTER(vp)]
         L.bpp_verifier_destroy.argtypes = [vp]
         L.bpp_verifier_destroy.restype = None

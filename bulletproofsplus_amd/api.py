@@ -333,6 +333,9 @@ class RangeProof:
             commitment_vec = commitment_vec.commitment_vec
         V = np.ascontiguousarray(np.asarray(commitment_vec, dtype=np.uint64).reshape(-1, a.PW))
         m = V.shape[0]
+        if len(pk.G_vec) != n * m or len(pk.H_vec) != n * m:
+            # the reference indexes pk.G_vec / H_vec with bounds-checked slices and panics (mulvec.rs:23-25)
+            raise AssertionError("pk must hold n*m generators")
         pts = np.ascontiguousarray(self.points_wire())
         sc = np.ascontiguousarray(self.scalars_wire())
         k = (pts.shape[0] - 3) // 2
@@ -353,6 +356,8 @@ class BatchVerifier:
     def __init__(self, pk: PublicKey, n: int, m: int, window_bits: int = 13):
         self.arith = pk.arith
         self.n, self.m = n, m
+        if len(pk.G_vec) != n * m or len(pk.H_vec) != n * m:
+            raise AssertionError("pk must hold n*m generators")       # range/mod.rs:90-91,252-253 assert_eq
         h = ctypes.c_void_p()
         G = np.ascontiguousarray(pk.G_vec)
         H = np.ascontiguousarray(pk.H_vec)
@@ -384,6 +389,8 @@ class BatchVerifier:
         pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, self.points_per_proof, self.arith.PW)
         sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
         count = pts.shape[0]
+        if sc.shape[0] != count:
+            raise RuntimeError("verify_wire: one scalar triple per proof record")
         ok = np.zeros(count, dtype=np.uint32)
         check(_lib.lib().bpp_range_verify_batch(self.handle, _ptr(pts), _ptr(sc), count, _ptr(ok)),
               "bpp_range_verify_batch")
@@ -395,6 +402,8 @@ class BatchVerifier:
         rec = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, self.points_per_proof, cb)
         sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
         count = rec.shape[0]
+        if sc.shape[0] != count:
+            raise RuntimeError("verify_compressed: one scalar triple per proof record")
         ok = np.zeros(count, dtype=np.uint32)
         check(_lib.lib().bpp_range_verify_batch_compressed(self.handle, _ptr(rec), _ptr(sc), count, _ptr(ok)),
               "bpp_range_verify_batch_compressed")
@@ -471,7 +480,21 @@ def _engine_prove_batch(self, values, gammas):
     return pts, sc, V
 
 
+def _engine_prover_workspace_bytes(self, count: int) -> int:
+    return _lib.lib().bpp_prover_workspace_bytes(self.handle, count)
+
+
+def _engine_prove_batch_device(self, d_values: int, d_gammas: int, count: int, d_out_points: int, d_out_scalars: int,
+                               d_out_V: int, d_workspace: int, workspace_bytes: int, stream: int = 0):
+    """prove_batch with every buffer in HBM (raw device pointers), asynchronous on `stream`."""
+    check(_lib.lib().bpp_range_prove_batch_device(self.handle, d_values, d_gammas, count, d_out_points, d_out_scalars,
+                                                  d_out_V or None, d_workspace, workspace_bytes, stream or None),
+          "bpp_range_prove_batch_device")
+
+
 BatchVerifier.prove_batch = _engine_prove_batch
+BatchVerifier.prover_workspace_bytes = _engine_prover_workspace_bytes
+BatchVerifier.prove_batch_device = _engine_prove_batch_device
 BatchVerifier.partial_bytes = _verifier_partial_bytes
 BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device

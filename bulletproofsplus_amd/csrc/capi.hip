@@ -133,6 +133,7 @@ extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const
     if (!v || !d_points || !d_scalars || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
     if (count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count too large for one launch");
+    HIPCHK(hipSetDevice(v->ctx.device));   // the launches must go to the device that holds this verifier's tables
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::run(v, d_points, d_scalars, count, d_challenges, d_ok, d_workspace,
                                              workspace_bytes, d_out_scalars, d_out_result,
@@ -147,6 +148,30 @@ extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, co
     HIPCHK(hipSetDevice(engine->ctx.device));
     return dispatch(engine->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V);
+    });
+}
+
+extern "C" size_t bpp_prover_workspace_bytes(const bpp_verifier* engine, size_t count) {
+    if (!engine) return 0;
+    size_t r = 0;
+    dispatch(engine->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::prove_layout(engine->s, count).total;
+        return 0;
+    });
+    return r;
+}
+
+extern "C" int bpp_range_prove_batch_device(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma,
+                                            size_t count, uint64_t* d_out_points, uint64_t* d_out_scalars,
+                                            uint64_t* d_out_V, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!engine || !d_v || !d_gamma || !d_out_points || !d_out_scalars || !d_workspace)
+        return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(engine->ctx.device));
+    return dispatch(engine->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::prove_batch_device(engine, d_v, d_gamma, count, d_out_points, d_out_scalars,
+                                                            d_out_V, d_workspace, workspace_bytes,
+                                                            static_cast<hipStream_t>(stream));
     });
 }
 
@@ -175,6 +200,7 @@ extern "C" int bpp_verifier_run_combined(bpp_verifier* v, const uint64_t* d_poin
                                          size_t workspace_bytes, void* stream) {
     if (!v || !d_points || !d_scalars || !d_out_partial || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
     if (count == 0) return fail(BPP_E_ARG, "empty batch");
+    HIPCHK(hipSetDevice(v->ctx.device));
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::run_combined(v, d_points, d_scalars, count, d_challenges, seed,
                                                       static_cast<uint32_t*>(d_out_partial), d_ok, d_workspace,
@@ -184,6 +210,7 @@ extern "C" int bpp_verifier_run_combined(bpp_verifier* v, const uint64_t* d_poin
 extern "C" int bpp_verifier_sum_partials(bpp_verifier* v, const void* d_partials, size_t n, uint32_t* d_ok,
                                          void* stream) {
     if (!v || !d_partials || !d_ok) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(v->ctx.device));
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::sum_partials(static_cast<const uint32_t*>(d_partials), n, d_ok,
                                                       static_cast<hipStream_t>(stream));

@@ -301,6 +301,62 @@ BPP_HD Xyzz<C> xyzz_madd(const Xyzz<C>& p, const Aff<C>& q) {
     r.ZZZ = fe_mul(p.ZZZ, PPP);
     return r;
 }
+// The same addition for the MSM inner loops, acc += (neg ? -q : q), with LAZY field additions (field.hpp,
+// fe_*_nr): no sum or difference inside the formula is reduced, the sign of q is folded into the one subtraction
+// that consumes q.y, and the exceptional cases are detected AFTER the fact from the new ZZ (ZZ3 = ZZ * Pp^2
+// vanishes iff the x-coordinates agree), so the common path carries one zero test instead of five.
+// q: canonical affine coordinates (x, y < p; x = y = 0 is infinity), as the tables and proof points hold them.
+// Invariants of the accumulator between calls (multiples of p, checked by tests/test_lazy_bounds.py with the
+// worst case of every step): X < 6p, Y <= 2p, ZZ, ZZZ < 1.1p; every product below has alpha * beta <= 40,
+// far under HEADROOM = R / p >= 630, so every Montgomery product comes out < 1.07 p.
+template <class C>
+BPP_HD void xyzz_madd_lazy(Xyzz<C>& p, const Aff<C>& q, bool neg) {
+    using P = typename C::Fp;
+    using F = Fe<P>;
+    uint32_t qz = 0;
+#pragma unroll
+    for (int i = 0; i < P::NL; i++) qz |= q.x.l[i] | q.y.l[i];
+    if (qz == 0) return;   // q is the point at infinity
+    if (p.is_inf()) {
+        p.X = q.x;
+        p.Y = neg ? fe_sub_nr<1>(F::zero(), q.y) : q.y;   // p - y <= p
+        p.ZZ = F::one();
+        p.ZZZ = F::one();
+        return;
+    }
+    const F U2 = fe_mul(q.x, p.ZZ);                 // < 1.01p
+    const F S2 = fe_mul(q.y, p.ZZZ);                // < 1.01p
+    const F Pp = fe_sub_nr<6>(U2, p.X);             // U2 - X1 + 6p          in (0, 7.1p)
+    const F R = fe_csub_nr<4>(S2, neg, p.Y);        // +-S2 - Y1 + 4p        in (0.9p, 5.1p)
+    const F PP = fe_sqr(Pp);                        // 7.1^2 / 630           < 1.09p
+    const F PPP = fe_mul(Pp, PP);                   // < 1.02p
+    const F Q = fe_mul(p.X, PP);                    // < 1.02p
+    const F u = fe_add_dbl_nr(PPP, Q);              // PPP + 2Q              < 3.1p
+    const F X3 = fe_sub_nr<4>(fe_sqr(R), u);        // R^2 - PPP - 2Q + 4p   in (0.9p, 5.1p)
+    const F T = fe_sub_nr<6>(Q, X3);                // Q - X3 + 6p           in (0.9p, 7.1p)
+    const F nY = fe_sub_nr<2>(F::zero(), p.Y);      // 2p - Y1               in [0, 2p]
+    const F ZZ3 = fe_mul(p.ZZ, PP);
+#if defined(BPP_LAZY_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    BPP_LAZY_CHECK(fe_below_kp<2>(U2) && fe_below_kp<2>(S2) && fe_below_kp<8>(Pp) && fe_below_kp<6>(R) &&
+                   fe_below_kp<2>(PP) && fe_below_kp<2>(PPP) && fe_below_kp<2>(Q) && fe_below_kp<4>(u) &&
+                   fe_below_kp<6>(X3) && fe_below_kp<8>(T) && fe_below_kp<3>(nY) && fe_below_kp<2>(ZZ3));
+#endif
+    if (ZZ3.is_zero()) {   // equal x: P + P or P + (-P)   (rare; the reference's case analysis, macros.rs:42-146)
+        if (fe_is_zero_mod<5>(R)) {
+            Aff<C> qq = q;
+            if (neg) qq.y = fe_sub_nr<1>(F::zero(), q.y);
+            p = xyzz_dbl_aff(qq);
+        } else {
+            p = xyzz_inf<C>();
+        }
+        return;
+    }
+    p.Y = fe_mul_add(R, T, nY, PPP);                // R (Q - X3) - Y1 PPP: (5.1 * 7.1 + 2 * 1.02) / 630 -> < 1.07p
+    p.X = X3;
+    p.ZZZ = fe_mul(p.ZZZ, PPP);
+    p.ZZ = ZZ3;
+}
+
 // jacobian image with Z = ZZ: (X * ZZ, Y * ZZZ, ZZ)
 template <class C>
 BPP_HD Jac<C> xyzz_to_jac(const Xyzz<C>& p) {

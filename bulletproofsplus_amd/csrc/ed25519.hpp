@@ -181,6 +181,11 @@ BPP_HD Xyzz<Ed25519> xyzz_madd(const Xyzz<Ed25519>& p, const Aff<Ed25519>& q) {
     r.e = jac_madd(p.e, q);
     return r;
 }
+// acc += (neg ? -q : q): the Edwards addition is complete and has no exceptional cases to defer, so the
+// "lazy" entry point of the MSM loops is the plain unified addition here
+BPP_HD void xyzz_madd_lazy(Xyzz<Ed25519>& p, const Aff<Ed25519>& q, bool neg) {
+    p.e = jac_madd(p.e, neg ? aff_neg(q) : q);
+}
 BPP_HD Jac<Ed25519> xyzz_to_jac(const Xyzz<Ed25519>& p) { return p.e; }
 
 // ---- memory images: affine x | y (2N words) ; extended X | Y | Z | T (4N words) --------------------------

@@ -148,34 +148,198 @@ BPP_HD Fe<P> fe_dbl(const Fe<P>& a) {
     return fe_add(a, a);
 }
 
-// Montgomery reduction of a 2*NL-limb normalised product T: returns T * R^-1 mod p.
-// Column-wise (product scanning): column k sums at most NL products < 2^60 plus a 30-bit limb and a
-// carry < 2^35, so the 64-bit accumulator cannot overflow.
+// ---- lazy ("nr" = not reduced) additions for straight-line formulas ---------------------------------------
+// The Montgomery radix leaves room above p (R / p = P::HEADROOM >= 630 for every field here): a product of
+// a < alpha p and b < beta p reduces to < p (1 + alpha beta / HEADROOM), and the column accumulators of
+// fe_mul only need NORMALISED limbs (< 2^30), not a reduced value.  So inside a formula a sum or difference
+// may skip the conditional subtraction altogether -- one carry pass, 3-5 instructions per limb instead of ~10
+// -- as long as the caller keeps track of the multiple of p each value stays below (<= 8 p here, so that
+// every product of two such values stays far below HEADROOM p^2).  Callers state their bounds in comments.
+
+// a + b (no reduction); the caller guarantees a + b < 2^(30 NL)
+template <class P>
+BPP_HD Fe<P> fe_add_nr(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    Fe<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t t = a.l[i] + b.l[i] + c;
+        r.l[i] = t & LIMB_MASK;
+        c = t >> LIMB_BITS;
+    }
+    return r;
+}
+
+// a - b + K p (no reduction); the caller guarantees b <= K p, so the value is in [0, a + K p]
+template <int K, class P>
+BPP_HD Fe<P> fe_sub_nr(const Fe<P>& a, const Fe<P>& b) {
+    static_assert(K >= 0 && K <= 8, "MODK holds 0..8 p");
+    constexpr int NL = P::NL;
+    Fe<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int32_t t = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)P::MODK[K][i] + c;
+        r.l[i] = (uint32_t)t & LIMB_MASK;
+        c = t >> LIMB_BITS;   // arithmetic: -1, 0 or 1
+    }
+    return r;
+}
+
+// (neg ? -a : a) - b + K p (no reduction); the caller guarantees a + b <= K p
+template <int K, class P>
+BPP_HD Fe<P> fe_csub_nr(const Fe<P>& a, bool neg, const Fe<P>& b) {
+    static_assert(K >= 0 && K <= 8, "MODK holds 0..8 p");
+    constexpr int NL = P::NL;
+    const int32_t s = neg ? -1 : 0;
+    Fe<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int32_t t = (((int32_t)a.l[i] ^ s) - s) - (int32_t)b.l[i] + (int32_t)P::MODK[K][i] + c;
+        r.l[i] = (uint32_t)t & LIMB_MASK;
+        c = t >> LIMB_BITS;
+    }
+    return r;
+}
+
+// a + 2 b (no reduction); the caller guarantees a + 2 b < 2^(30 NL)
+template <class P>
+BPP_HD Fe<P> fe_add_dbl_nr(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    Fe<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t t = a.l[i] + (b.l[i] << 1) + c;   // < 3 * 2^30 + 3
+        r.l[i] = t & LIMB_MASK;
+        c = t >> LIMB_BITS;
+    }
+    return r;
+}
+
+// value == 0 mod p for a normalised value in [0, (KMAX + 1) p): compares with 0, p, .., KMAX p (the slow,
+// exact test -- lazy formulas reach it only on their exceptional paths)
+template <int KMAX, class P>
+BPP_HD bool fe_is_zero_mod(const Fe<P>& a) {
+    static_assert(KMAX >= 0 && KMAX <= 8, "MODK holds 0..8 p");
+    bool z = false;
+#pragma unroll
+    for (int k = 0; k <= KMAX; k++) {
+        uint32_t q = 0;
+#pragma unroll
+        for (int i = 0; i < P::NL; i++) q |= a.l[i] ^ P::MODK[k][i];
+        z = z || q == 0;
+    }
+    return z;
+}
+
+// normalised value < K p ?  (bound checks of the lazy formulas in host-side tests)
+template <int K, class P>
+BPP_HD bool fe_below_kp(const Fe<P>& a) {
+    static_assert(K >= 0 && K <= 8, "MODK holds 0..8 p");
+    for (int i = P::NL - 1; i >= 0; i--) {
+        if (a.l[i] >> LIMB_BITS) return false;   // not normalised
+        if (a.l[i] != P::MODK[K][i]) return a.l[i] < P::MODK[K][i];
+    }
+    return false;
+}
+
+// ---- the multiplier ------------------------------------------------------------------------------------------
+// Column-wise (product scanning) with ONE 64-bit running accumulator: column k sums at most NL products < 2^60
+// plus a carry < 2^35, which cannot overflow; per column one mask (the limb) and one 64-bit shift (the carry).
+//
+// What the hardware wants (measured on MI355X, tools/ubench.hip, profiles/ubench_r02.json): one wave issues a
+// v_mad_u64_u32 every ~9.6 clocks whether or not it depends on the previous one, so instruction-level
+// parallelism inside a wave buys nothing for this instruction -- the SIMD's second wave fills the pipe -- and
+// every other instruction costs its full issue slot (v_mad + v_lshrrev_b64 back to back run at the SUM of their
+// costs: nothing hides in the multiplier's shadow).  Left to itself the compiler reassociates the column sums to
+// shorten the dependency chain: every column starts from zero and the previous column's carry is merged with
+// an extra 64-bit add (52 v_lshl_add_u64 and ~25 v_mov per product).  An empty asm on the accumulator at the
+// end of each column stops the reassociation there: the carry stays the addend of the column's first
+// multiply-add, one chain, no merge instructions.  (Writing the multiply-adds themselves as inline asm is worse:
+// the compiler must assume the gfx940 dst-forwarding hazard after every asm and pads each with an s_nop.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BPP_NO_CHAIN_BARRIER)
+#define BPP_CHAIN_BARRIER(acc) asm volatile("" : "+v"(acc))
+// the constant 1 in a register the compiler cannot see through: `acc += x * one` is then emitted as ONE
+// v_mad_u64_u32 instead of a zero-extension (v_mov) plus a 64-bit add
+__device__ __forceinline__ uint32_t opaque_one() {
+    uint32_t one;
+    asm("v_mov_b32 %0, 1" : "=v"(one));
+    return one;
+}
+// the same barrier over the accumulator AND the reduction multipliers found so far, in one statement: all of them
+// then look equally "late" to the reassociation, which keeps the carry as the seed of the next column's chain
+// (otherwise the products of the early multipliers are summed on their own and merged with a 64-bit add)
+template <int CNT>
+__device__ __forceinline__ void chain_barrier_m(uint64_t& acc, uint32_t* m) {
+    static_assert(CNT >= 0 && CNT <= 13, "operand limit of one asm statement");
+    if constexpr (CNT == 0) asm volatile("" : "+v"(acc));
+    if constexpr (CNT == 1) asm volatile("" : "+v"(acc), "+v"(m[0]));
+    if constexpr (CNT == 2) asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]));
+    if constexpr (CNT == 3) asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]));
+    if constexpr (CNT == 4) asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]));
+    if constexpr (CNT == 5) asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]));
+    if constexpr (CNT == 6)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+    if constexpr (CNT == 7)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]));
+    if constexpr (CNT == 8)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]));
+    if constexpr (CNT == 9)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]), "+v"(m[8]));
+    if constexpr (CNT == 10)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]), "+v"(m[8]), "+v"(m[9]));
+    if constexpr (CNT == 11)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]));
+    if constexpr (CNT == 12)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]));
+    if constexpr (CNT == 13)
+        asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
+                          "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), "+v"(m[12]));
+}
+#else
+#define BPP_CHAIN_BARRIER(acc) ((void)0)
+BPP_HD uint32_t opaque_one() { return 1u; }
+template <int CNT>
+BPP_HD void chain_barrier_m(uint64_t&, uint32_t*) {}
+#endif
+
+// Montgomery reduction of a 2*NL-limb product T (limbs < 2^31): returns T * R^-1 mod p.
+// Column k sums at most NL products < 2^60, a limb < 2^31 and a carry < 2^35: no overflow.
 template <class P>
 BPP_HD Fe<P> fe_mont_reduce(const uint32_t* T) {
     constexpr int NL = P::NL;
     uint32_t m[NL];
     Fe<P> r;
     uint64_t acc = 0;
+    const uint32_t one = opaque_one();
 #pragma unroll
     for (int k = 0; k < NL; k++) {
-        acc += T[k];
+        acc += (uint64_t)T[k] * one;
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::MOD[k - i];
         m[k] = ((uint32_t)acc * P::INV) & LIMB_MASK;
         acc += (uint64_t)m[k] * P::MOD[0];
         acc >>= LIMB_BITS;
+        BPP_CHAIN_BARRIER(acc);
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL; k++) {
-        acc += T[k];
+        acc += (uint64_t)T[k] * one;
 #pragma unroll
         for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P::MOD[k - i];
         r.l[k - NL] = (uint32_t)acc & LIMB_MASK;
         acc >>= LIMB_BITS;
+        BPP_CHAIN_BARRIER(acc);
     }
-    // (T + m p) / R < T / R + p, which is < 2p for every caller (products of values < 2p: T < 4 p^2 and
-    // 4p < R)  =>  acc == 0 here and the result already satisfies the [0, 2p) invariant
+    // (T + m p) / R < T / R + p: far below 2p for every caller (T < HEADROOM / 8 p^2)  =>  acc == 0 here
     return r;
 }
 
@@ -187,67 +351,116 @@ BPP_HD void fe_mul_wide(const Fe<P>& a, const Fe<P>& b, uint32_t* T) {
 #pragma unroll
     for (int k = 0; k < 2 * NL - 1; k++) {
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++)
-            acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
         T[k] = (uint32_t)acc & LIMB_MASK;
         acc >>= LIMB_BITS;
+        BPP_CHAIN_BARRIER(acc);
     }
     T[2 * NL - 1] = (uint32_t)acc;
 }
 
-// Montgomery product a*b*R^-1 mod p: NL^2 v_mad_u64_u32 for the product, NL^2 + NL for the reduction.
-template <class P>
-BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
-    uint32_t T[2 * P::NL];
-    fe_mul_wide(a, b, T);
-    return fe_mont_reduce<P>(T);
+// ---- fused product + Montgomery reduction ------------------------------------------------------------------
+// fe_mul / fe_sqr / fe_mul_add run the product and its reduction in ONE pass over the 2 NL columns.  Column k
+// receives na(k) = min(k, 2NL-2-k) + 1 plain products (W times that for the two-product form) and nm(k) =
+// (k < NL ? k + 1 : 2NL-1-k) products m_i p_j of the reduction.  Where W na + nm <= 15 -- the outer columns --
+// they all fit one 64-bit accumulator (15 * 2^60 + carry < 2^64), so the column needs no intermediate limb
+// T[k] at all: no mask, no second shift, no re-entry of T[k] into the reduction chain.  Only the middle
+// columns (k = 7..17 of 26 for the 13-limb field, k = 7..9 of 18 for the 9-limb fields) would overflow; there
+// the plain products run in a second accumulator whose limb enters the reduction chain as T * 1 (one
+// multiply-add).  Per 13-limb product: 338 + 11 v_mad_u64_u32, 37 masks, 37 64-bit shifts, 13 v_mul_lo_u32,
+// against 338 v_mad + 60 v_lshl_add_u64 + 48 shifts + 51 masks + 25 v_mov + 13 v_mul_lo of the two-pass form
+// as the compiler scheduled it.
+//   col(k, acc): adds the plain products of column k (k <= 2NL-2) to acc.
+template <class P, int W, int K, class ColFn>
+BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t* m, Fe<P>& r, uint32_t one) {
+    constexpr int NL = P::NL;
+    constexpr int na = K <= 2 * NL - 2 ? (K < 2 * NL - 2 - K ? K : 2 * NL - 2 - K) + 1 : 0;
+    constexpr int nm = K < NL ? K + 1 : 2 * NL - 1 - K;
+    constexpr bool fused = W * na + nm <= 15;
+    // the column before this one: was it split?  (its plain-product chain then holds a carry for this column)
+    constexpr int nap = K >= 1 ? ((K - 1) < 2 * NL - 2 - (K - 1) ? (K - 1) : 2 * NL - 2 - (K - 1)) + 1 : 0;
+    constexpr int nmp = K >= 1 ? ((K - 1) < NL ? K : 2 * NL - K) : 0;
+    constexpr bool prev_split = K >= 1 && !(W * nap + nmp <= 15);
+    if constexpr (!fused) {
+        if constexpr (!prev_split) accA = 0;
+        col(K, accA);
+        const uint32_t T = (uint32_t)accA & LIMB_MASK;
+        accA >>= LIMB_BITS;
+        BPP_CHAIN_BARRIER(accA);
+        accB += (uint64_t)T * one;
+    } else {
+        if constexpr (prev_split) accB += accA;
+        if constexpr (na > 0) col(K, accB);
+    }
+    if constexpr (K < NL) {
+#pragma unroll
+        for (int i = 0; i < K; i++) accB += (uint64_t)m[i] * P::MOD[K - i];
+        m[K] = ((uint32_t)accB * P::INV) & LIMB_MASK;
+        accB += (uint64_t)m[K] * P::MOD[0];
+    } else {
+#pragma unroll
+        for (int i = K - NL + 1; i < NL; i++) accB += (uint64_t)m[i] * P::MOD[K - i];
+        r.l[K - NL] = (uint32_t)accB & LIMB_MASK;
+    }
+    accB >>= LIMB_BITS;
+    if constexpr (K + 1 < 2 * NL) {
+        // the multipliers column K + 1 reads: m[lo .. hi)
+        constexpr int lo = K + 1 < NL ? 0 : K + 1 - NL + 1;
+        constexpr int hi = K + 1 < NL ? K + 1 : NL;
+        chain_barrier_m<(hi > lo ? hi - lo : 0)>(accB, m + lo);
+        fe_fused_column<P, W, K + 1>(col, accA, accB, m, r, one);
+    }
 }
 
-// (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: the two double-width products are added limb by
-// limb (each limb < 2^31, which the reduction's column accumulator absorbs) and reduced together.  For
-// operands < 2p the sum is < 8 p^2, and 8p / R < 1/32 for every field here, so the result is < 1.04 p: the
-// [0, 2p) invariant holds.  Saves NL^2 + NL of the 3 NL^2 + NL multiplier operations of two separate products.
+template <class P, int W, class ColFn>
+BPP_HD Fe<P> fe_fused_reduce(ColFn&& col) {
+    uint32_t m[P::NL];
+    Fe<P> r;
+    uint64_t accB = 0, accA = 0;   // reduction chain (and the fused columns); plain-product chain of the middle columns
+    fe_fused_column<P, W, 0>(col, accA, accB, m, r, opaque_one());
+    // (T + m p) / R < T / R + p: far below 2p for every caller (T < HEADROOM / 8 p^2)  =>  accB == 0 here
+    return r;
+}
+
+// Montgomery product a*b*R^-1 mod p.  For a < alpha p, b < beta p the result is < p (1 + alpha beta / HEADROOM).
+template <class P>
+BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    constexpr int NL = P::NL;
+    return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
+#pragma unroll
+        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+    });
+}
+
+// (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: < p (1 + (alpha beta + gamma delta) / HEADROOM).
+// Saves NL^2 + NL of the 3 NL^2 + NL multiplier operations of two separate products.
 template <class P>
 BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
     constexpr int NL = P::NL;
-    uint32_t T[2 * NL], U[2 * NL];
-    fe_mul_wide(a, b, T);
-    fe_mul_wide(c, d, U);
+    return fe_fused_reduce<P, 2>([&](int k, uint64_t& acc) {
 #pragma unroll
-    for (int i = 0; i < 2 * NL; i++) T[i] += U[i];
-    return fe_mont_reduce<P>(T);
+        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+    });
 }
 
-// Montgomery square: the NL(NL-1)/2 cross products are computed once, against a pre-doubled copy of the
-// operand (2 a_j < 2^31, so a column of <= 6 cross products + 1 square stays below 2^64), in ONE running
-// column accumulator exactly like fe_mul: 91 v_mad_u64_u32 instead of 169 for the product phase.
+// Montgomery square: the NL(NL-1)/2 cross products are computed once, against a pre-doubled copy of the operand
+// (2 a_j < 2^31: a cross product counts as two plain ones in the column bound, which is what it replaces):
+// 91 v_mad_u64_u32 instead of 169 for the product part.
 template <class P>
 BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
-#if defined(BPP_SQR_OPAQUE) && defined(__HIP_DEVICE_COMPILE__)
-    Fe<P> b = a;
-#pragma unroll
-    for (int i = 0; i < P::NL; i++) asm volatile("" : "+v"(b.l[i]));
-    return fe_mul(a, b);
-#elif defined(BPP_SQR_VIA_MUL)
-    return fe_mul(a, a);
-#endif
     constexpr int NL = P::NL;
     uint32_t a2[NL];
 #pragma unroll
     for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
-    uint32_t T[2 * NL];
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < 2 * NL - 1; k++) {
+    return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
         // pairs i < j, i + j = k
 #pragma unroll
         for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (uint64_t)a.l[i] * a2[k - i];
         if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-        T[k] = (uint32_t)acc & LIMB_MASK;
-        acc >>= LIMB_BITS;
-    }
-    T[2 * NL - 1] = (uint32_t)acc;
-    return fe_mont_reduce<P>(T);
+    });
 }
 
 // ---- memory / wire formats -----------------------------------------------------------------------

@@ -334,12 +334,59 @@ struct VerifyImpl {
         return BPP_OK;
     }
 
-    // ---- batched prover (prover_batch.hpp): host buffers in, host buffers out -------------------------
-    static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
-                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+    // ---- batched prover (prover_batch.hpp) -------------------------------------------------------------
+    // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
+    // and nothing synchronises.  The batch is processed in chunks that reuse one workspace.
+    struct ProveLayout {
+        size_t a, b, cG, cH, pwy, con, vps, part, vout, total;
+        size_t chunk;
+        unsigned per;
+    };
+    static size_t prove_chunk(const VerifyShape& s, size_t count) {
+        const uint32_t nvp = pb_num_vps(s.k, s.m);
+        const size_t chunk_max = std::max<size_t>(1, std::min<size_t>(1024, ((size_t)6 << 30) / ((size_t)nvp * s.N * 32)));
+        return std::min(chunk_max, std::max<size_t>(count, 1));
+    }
+    static ProveLayout prove_layout(const VerifyShape& s, size_t count) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        ProveLayout w;
+        const uint32_t nvp = pb_num_vps(s.k, s.m);
+        w.chunk = prove_chunk(s, count);
+        const size_t nv_total = w.chunk * nvp;
+        w.per = blocks_per_proof(s, nv_total);
+        const size_t vec = w.chunk * (size_t)s.mn * 32;
+        size_t o = 0;
+        w.a = o;
+        o += al(vec);
+        w.b = o;
+        o += al(vec);
+        w.cG = o;
+        o += al(vec);
+        w.cH = o;
+        o += al(vec);
+        w.pwy = o;
+        o += al(vec);
+        w.con = o;
+        o += al(w.chunk * (size_t)pb_consts_elems(s.k) * 32);
+        w.vps = o;
+        o += al(nv_total * (size_t)s.N * 32);
+        w.part = o;
+        o += al(nv_total * w.per * JW * 4);
+        w.vout = o;
+        o += al(w.chunk * (size_t)s.m * WW * 4);   // the commitments of a chunk when the caller does not want them
+        w.total = o;
+        return w;
+    }
+    // d_values: count x m u64 ; d_gammas: count x m scalars ; d_out_points: count x (3 + 2k) wire points ;
+    // d_out_scalars: count x 3 scalars ; d_out_V: count x m wire points (may be null)
+    static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
+                                  uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, void* d_workspace,
+                                  size_t workspace_bytes, hipStream_t st) {
         const VerifyShape& s = v->s;
-        const uint32_t k = s.k, m = s.m, mn = s.mn;
+        const uint32_t k = s.k, m = s.m;
         const uint32_t nvp = pb_num_vps(k, m);
+        const ProveLayout L = prove_layout(s, count);
+        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
         ProverConsts pc;
         pc.alpha = m == 1 ? 7 : 33;   // range/mod.rs:94 / :256
         pc.d_L = 4;                   // wip.rs:94
@@ -348,50 +395,58 @@ struct VerifyImpl {
         pc.s = 44;
         pc.delta = 88;
         pc.eta = 123;
-        const size_t chunk_max = std::max<size_t>(1, std::min<size_t>(1024, ((size_t)6 << 30) / ((size_t)nvp * s.N * 32)));
-        hipStream_t st = nullptr;
-        for (size_t base = 0; base < count; base += chunk_max) {
-            const size_t cnt = std::min(chunk_max, count - base);
+        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+        auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+        for (size_t base = 0; base < count; base += L.chunk) {
+            const size_t cnt = std::min(L.chunk, count - base);
             const size_t nv_total = cnt * nvp;
-            const unsigned per = blocks_per_proof(s, nv_total);
-            DevBuf d_val, d_gam, d_a, d_b, d_cG, d_cH, d_pwy, d_con, d_vps, d_part, d_pts, d_V, d_sc;
-            HIPCHK(d_val.alloc(cnt * m * 8));
-            HIPCHK(hipMemcpyAsync(d_val.p, values + base * m, cnt * m * 8, hipMemcpyHostToDevice, st));
-            int rc = upload_scalars<C>(gammas + base * m * 4, cnt * m, d_gam, st);
-            if (rc) return rc;
-            const size_t vec = cnt * (size_t)mn * 32;
-            HIPCHK(d_a.alloc(vec));
-            HIPCHK(d_b.alloc(vec));
-            HIPCHK(d_cG.alloc(vec));
-            HIPCHK(d_cH.alloc(vec));
-            HIPCHK(d_pwy.alloc(vec));
-            HIPCHK(d_con.alloc(cnt * (size_t)pb_consts_elems(k) * 32));
-            HIPCHK(d_vps.alloc(nv_total * (size_t)s.N * 32));
-            HIPCHK(d_part.alloc(nv_total * per * JW * 4));
-            HIPCHK(d_pts.alloc(cnt * (size_t)(3 + 2 * k) * WW * 4));
-            HIPCHK(d_V.alloc(cnt * (size_t)m * WW * 4));
-            HIPCHK(d_sc.alloc(cnt * 3 * 32));
-            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc,
-                               static_cast<const uint64_t*>(d_val.p), d_gam.u32(), v->challenges.u32(), 0u, d_a.u32(),
-                               d_b.u32(), d_cG.u32(), d_cH.u32(), d_pwy.u32(), d_con.u32(), d_vps.u32());
+            // the launch geometry is the one the workspace was sized for (a smaller last chunk may use fewer blocks)
+            const unsigned per = std::min(L.per, blocks_per_proof(s, nv_total));
+            uint32_t* o_pts = reinterpret_cast<uint32_t*>(d_out_points) + base * (size_t)(3 + 2 * k) * WW;
+            uint32_t* o_sc = reinterpret_cast<uint32_t*>(d_out_scalars) + base * 24;
+            uint32_t* o_V = d_out_V ? reinterpret_cast<uint32_t*>(d_out_V) + base * (size_t)m * WW : W(L.vout);
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_values + base * m,
+                               reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8, v->challenges.u32(), 0u,
+                               W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
             for (uint32_t t = 0; t < k; t++)
-                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, d_a.u32(), d_b.u32(),
-                                   d_cG.u32(), d_cH.u32(), d_pwy.u32(), d_con.u32(), d_vps.u32());
-            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_a.u32(), d_b.u32(),
-                               d_cG.u32(), d_cH.u32(), d_con.u32(), d_vps.u32(), d_sc.u32());
-            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK),
-                               fixed_lds<C>(), st, s, d_vps.u32(), v->table.u32(), d_part.u32(), per, 0u,
-                               (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0, 0u);
-            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, d_part.u32(), per,
-                               d_pts.u32(), d_V.u32(), nv_total);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(out_points + base * (3 + 2 * k) * PW, d_pts.p, cnt * (size_t)(3 + 2 * k) * WW * 4,
-                                  hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(out_scalars + base * 12, d_sc.p, cnt * 96, hipMemcpyDeviceToHost, st));
-            if (out_V)
-                HIPCHK(hipMemcpyAsync(out_V + base * m * PW, d_V.p, cnt * (size_t)m * WW * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, W(L.a), W(L.b), W(L.cG),
+                                   W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, W(L.a), W(L.b), W(L.cG),
+                               W(L.cH), W(L.con), W(L.vps), o_sc);
+            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st,
+                               s, W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
+                               (uint32_t*)nullptr, (size_t)0, 0u);
+            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, W(L.part), per, o_pts, o_V,
+                               nv_total);
         }
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+
+    // host buffers in, host buffers out
+    static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
+                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+        const VerifyShape& s = v->s;
+        const uint32_t k = s.k, m = s.m;
+        hipStream_t st = nullptr;
+        const ProveLayout L = prove_layout(s, count);
+        DevBuf d_val, d_gam, d_pts, d_V, d_sc, d_ws;
+        HIPCHK(d_val.alloc(count * m * 8));
+        HIPCHK(hipMemcpyAsync(d_val.p, values, count * m * 8, hipMemcpyHostToDevice, st));
+        int rc = upload_scalars<C>(gammas, count * m, d_gam, st);
+        if (rc) return rc;
+        HIPCHK(d_pts.alloc(count * (size_t)(3 + 2 * k) * WW * 4));
+        HIPCHK(d_V.alloc(count * (size_t)m * WW * 4));
+        HIPCHK(d_sc.alloc(count * 3 * 32));
+        HIPCHK(d_ws.alloc(L.total));
+        rc = prove_batch_device(v, static_cast<const uint64_t*>(d_val.p), static_cast<const uint64_t*>(d_gam.p), count,
+                                static_cast<uint64_t*>(d_pts.p), static_cast<uint64_t*>(d_sc.p),
+                                static_cast<uint64_t*>(d_V.p), d_ws.p, L.total, st);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(out_points, d_pts.p, count * (size_t)(3 + 2 * k) * WW * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out_scalars, d_sc.p, count * 96, hipMemcpyDeviceToHost, st));
+        if (out_V) HIPCHK(hipMemcpyAsync(out_V, d_V.p, count * (size_t)m * WW * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         return BPP_OK;
     }
 

@@ -909,11 +909,10 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
             raw[4 * k + 2] = v.z;
             raw[4 * k + 3] = v.w;
         }
-        const bool valid = (vbits >> slot) & 1u;
-        Aff<C> cur = aff_load<C>(raw);
-        if ((nbits >> slot) & 1u) cur = aff_neg(cur);
+        const bool valid = (vbits >> slot) & 1u, neg = (nbits >> slot) & 1u;
+        const Aff<C> cur = aff_load<C>(raw);
         issue();   // step t + FIXED_RING goes into the slot just read
-        if (valid) acc = xyzz_madd(acc, cur);
+        if (valid) xyzz_madd_lazy(acc, cur, neg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs have landed: LDS may be reused
     if (ROLE == 0) {
@@ -1027,16 +1026,13 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
     for (uint32_t v = 0; v < s.NV; v++) {
         const int32_t d = d_next;
         Aff<C> cur;
-        if (d) {
-            cur = aff_load<C>(raw);
-            if (d < 0) cur = aff_neg(cur);
-        }
+        if (d) cur = aff_load<C>(raw);
         if (v + 1 < s.NV) {
             d_next = (int32_t)dg[(size_t)(v + 1) * VAR_DIGIT_STRIDE] - 8;
             if (d_next)
                 ld_words<2 * N>(T + ((size_t)(v + 1) * VAR_MULTIPLES + (d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
         }
-        if (d) acc = xyzz_madd(acc, cur);
+        if (d) xyzz_madd_lazy(acc, cur, d < 0);
     }
     jac_stg<C>(wsum + lane * JW, xyzz_to_jac(acc));
 }

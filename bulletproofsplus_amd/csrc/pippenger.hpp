@@ -168,9 +168,8 @@ __global__ void __launch_bounds__(128, 2) k_pip_buckets(PipShape s, const uint32
     Xyzz<C> acc = xyzz_inf<C>();
     for (uint32_t t = 0; t < cnt; t++) {
         const uint32_t e = row[beg + t];
-        Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
-        if (e & 1u) q = aff_neg(q);
-        acc = xyzz_madd(acc, q);
+        const Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
+        xyzz_madd_lazy(acc, q, (e & 1u) != 0);
     }
     jac_stg<C>(buckets + gid * JW, xyzz_to_jac(acc));
 }
@@ -199,9 +198,8 @@ __global__ void __launch_bounds__(128, 2) k_pip_heavy(PipShape s, const uint32_t
         Xyzz<C> acc = xyzz_inf<C>();
         for (uint32_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
             const uint32_t e = row[t];
-            Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
-            if (e & 1u) q = aff_neg(q);
-            acc = xyzz_madd(acc, q);
+            const Aff<C> q = aff_ldg<C>(points + (size_t)(e >> 1) * 2 * N);
+            xyzz_madd_lazy(acc, q, (e & 1u) != 0);
         }
         Jac<C> sum = block_reduce_jac<C>(xyzz_to_jac(acc), lds);
         if (threadIdx.x == 0) jac_stg<C>(heavy_parts + ((size_t)h * PIP_SPLIT + blockIdx.y) * JW, sum);

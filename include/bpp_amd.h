@@ -150,6 +150,15 @@ int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *
 int bpp_range_prove_batch(bpp_verifier *engine, const uint64_t *v, const uint64_t *gamma, size_t count,
                           uint64_t *out_points, uint64_t *out_scalars, uint64_t *out_V);
 
+/* The same pass with every buffer in HBM (what bench.py's `prove` leg times): d_v count x m uint64_t, d_gamma
+ * count x m scalars, outputs as above (d_out_V may be NULL), asynchronous on `stream`; no host memory is touched
+ * and nothing synchronises.  The batch is processed in chunks that reuse d_workspace
+ * (bpp_prover_workspace_bytes(engine, count) bytes). */
+size_t bpp_prover_workspace_bytes(const bpp_verifier *engine, size_t count);
+int bpp_range_prove_batch_device(bpp_verifier *engine, const uint64_t *d_v, const uint64_t *d_gamma, size_t count,
+                                 uint64_t *d_out_points, uint64_t *d_out_scalars, uint64_t *d_out_V,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- combined batch check ("final multiscalar check") -- an engine mode, NOT a reference code path ----
  * One random linear combination of the batch's verification MulVecs, sum_p w_p * M_p == identity, with
  * w_p = 128-bit odd values from SplitMix64(seed, p) (csrc/combined.hpp): the fixed generators collapse

@@ -334,6 +334,37 @@ static void mulvec_calc(const curve_t *c, pt_t *out, const fe_t *scalars, const 
     *out = sum;
 }
 
+/* The same sum by the bucket method (Pippenger), c-bit unsigned windows: what a tuned CPU library would run
+ * instead of the reference's naive loop.  NOT a reference code path -- it exists only so that bench.py can time
+ * a "CPU-Pippenger" baseline beside the reference-semantics one (BASELINE.md plan item 3); tests check that it
+ * returns the same point as mulvec_calc. */
+static void mulvec_pippenger(const curve_t *c, pt_t *out, const fe_t *scalars, const pt_t *points, size_t n, int cbits) {
+    const int nb = (1 << cbits) - 1, windows = (256 + cbits - 1) / cbits;
+    u64 *k = (u64 *)malloc(sizeof(u64) * 4 * (n ? n : 1));
+    pt_t *bucket = (pt_t *)malloc(sizeof(pt_t) * nb);
+    for (size_t i = 0; i < n; i++) fr_to_k(c, k + 4 * i, &scalars[i]);
+    pt_t acc; pt_set_inf(c, &acc);
+    for (int w = windows - 1; w >= 0; w--) {
+        for (int t = 0; t < cbits; t++) pt_dbl(c, &acc, &acc);
+        for (int b = 0; b < nb; b++) pt_set_inf(c, &bucket[b]);
+        const int bit = w * cbits;
+        for (size_t i = 0; i < n; i++) {
+            u64 d = k[4 * i + bit / 64] >> (bit % 64);
+            if (bit % 64 + cbits > 64 && bit / 64 + 1 < 4) d |= k[4 * i + bit / 64 + 1] << (64 - bit % 64);
+            d &= (u64)nb;
+            if (d) pt_add(c, &bucket[d - 1], &bucket[d - 1], &points[i]);
+        }
+        pt_t run, sum; pt_set_inf(c, &run); pt_set_inf(c, &sum);
+        for (int b = nb - 1; b >= 0; b--) {      /* sum_b (b+1) bucket[b] by running sums */
+            pt_add(c, &run, &run, &bucket[b]);
+            pt_add(c, &sum, &sum, &run);
+        }
+        pt_add(c, &acc, &acc, &sum);
+    }
+    *out = acc;
+    free(k); free(bucket);
+}
+
 /* ------------------------------------------------------------------------------------------
  * util.rs
  * ---------------------------------------------------------------------------------------- */
@@ -818,7 +849,8 @@ EXPORT int orc_range_prove(int curve, const u64 *gh, const u64 *G, const u64 *H,
  * Returns 0 = Ok(()), 1 = Err(VerificationError), negative = usage error.
  * out_scalars (optional): the N = 2mn+2k+m+5 MulVec scalars in MulVec order (N x 4 limbs).
  * out_result (optional): the MulVec result point.  If skip_msm != 0 only the scalars are produced
- * (return value 0). */
+ * (return value 0); skip_msm in 2..16 selects the bucket-method MulVec of that window width (same result
+ * point; used only as bench.py's "CPU-Pippenger" baseline). */
 EXPORT int orc_range_verify(int curve, const u64 *gh, const u64 *G, const u64 *H, size_t n, size_t m,
                             const u64 *proof_points, size_t k, const u64 *proof_scalars, const u64 *V,
                             u64 *out_scalars, u64 *out_result, int skip_msm) {
@@ -845,8 +877,10 @@ EXPORT int orc_range_verify(int curve, const u64 *gh, const u64 *G, const u64 *H
     int rc = verify_build(c, &pk, n, m, &A, &w, Vp, sc, ps);
     if (rc == 0) {
         if (out_scalars) for (size_t i = 0; i < N; i++) fe_from_mont(&c->fr, out_scalars + 4 * i, &sc[i]);
-        if (!skip_msm) {
-            pt_t res; mulvec_calc(c, &res, sc, ps, N);
+        if (skip_msm != 1) {   /* 0: the reference's naive MulVec ; 2..16: bucket method with that window width */
+            pt_t res;
+            if (skip_msm >= 2 && skip_msm <= 16) mulvec_pippenger(c, &res, sc, ps, N, skip_msm);
+            else mulvec_calc(c, &res, sc, ps, N);
             if (out_result) pt_to_wire(c, out_result, &res);
             rc = pt_is_inf(c, &res) ? 0 : 1;
         }

@@ -223,8 +223,10 @@ def range_prove(pk: PublicKey, n: int, values, gammas, V=None, faithful_timing=F
 
 
 def range_verify(pk: PublicKey, n: int, m: int, proof_points, proof_scalars, V,
-                 want_scalars=False, want_result=False, skip_msm=False):
-    """RangeProof::verify.  Returns rc (0 Ok / 1 VerificationError) or a tuple with the extras."""
+                 want_scalars=False, want_result=False, skip_msm=False, pippenger_window=0):
+    """RangeProof::verify.  Returns rc (0 Ok / 1 VerificationError) or a tuple with the extras.
+    pippenger_window in 2..16: the final MulVec by the bucket method instead of the reference's naive loop
+    (same point; bench.py's "CPU-Pippenger" baseline)."""
     curve = pk.curve
     PW = point_words(curve)
     proof_points = np.ascontiguousarray(proof_points, dtype=np.uint64).reshape(-1, PW)
@@ -239,7 +241,8 @@ def range_verify(pk: PublicKey, n: int, m: int, proof_points, proof_scalars, V,
     rc = lib().orc_range_verify(curve, _p(pk.gh), _p(G), _p(H), ctypes.c_size_t(n), ctypes.c_size_t(m),
                                 _p(proof_points), ctypes.c_size_t(k), _p(proof_scalars), _p(V),
                                 _p(sc) if sc is not None else None,
-                                _p(res) if res is not None else None, 1 if skip_msm else 0)
+                                _p(res) if res is not None else None,
+                                1 if skip_msm else (int(pippenger_window) if 2 <= int(pippenger_window) <= 16 else 0))
     if not want_scalars and not want_result:
         return rc
     return rc, sc, res

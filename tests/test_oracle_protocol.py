@@ -86,3 +86,20 @@ def test_oracle_prove_c1(golden):
     assert O.wire_to_points(curve, pts) == [hexpt(curve, h) for h in full["points"]]
     assert "%064x" % O.wire_to_scalars(sc)[0] == full["r_prime"]
     assert O.range_verify(pk, 32, 1, pts, sc, V) == 0
+
+
+def test_oracle_pippenger_mulvec_equals_naive():
+    """The bucket-method MulVec of the oracle (bench.py's CPU-Pippenger baseline only) returns the same result point
+    and verdict as the reference-semantics naive MulVec, for valid and tampered proofs, several window widths."""
+    import oracle as O
+    for curve in (O.BLS12_381, O.SECP256K1):
+        pk = O.PublicKey(curve, 16)
+        pts, sc, V = O.range_prove(pk, 8, [200, 5], [3, 7])
+        bad = sc.copy()
+        bad[1, 0] ^= 4
+        for scal, want in ((sc, 0), (bad, 1)):
+            rc0, _, res0 = O.range_verify(pk, 8, 2, pts, scal, V, want_result=True)
+            assert rc0 == want
+            for w in (2, 5, 8, 11):
+                rc, _, res = O.range_verify(pk, 8, 2, pts, scal, V, want_result=True, pippenger_window=w)
+                assert rc == want and np.array_equal(res, res0), (curve, w)

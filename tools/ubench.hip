@@ -19,11 +19,11 @@ constexpr int CHAINS = 8;
 //       6 v_lshrrev_b64, 7 v_mul_hi_u32, 8 v_add_u32, 9 v_add3_u32
 template <int KIND>
 __global__ void __launch_bounds__(256) k_inst(uint64_t* out, uint32_t seed) {
-    uint64_t a[CHAINS];
+    uint64_t a[CHAINS], b[CHAINS];
     uint32_t x = seed + threadIdx.x, y = seed * 3 + 7;
     double d[CHAINS];
 #pragma unroll
-    for (int c = 0; c < CHAINS; c++) { a[c] = seed + c; d[c] = 1.0 + c; }
+    for (int c = 0; c < CHAINS; c++) { a[c] = seed + c; b[c] = seed * 5 + c; d[c] = 1.0 + c; }
     for (int it = 0; it < ITERS; it++) {
 #pragma unroll
         for (int c = 0; c < CHAINS; c++) {
@@ -37,11 +37,22 @@ __global__ void __launch_bounds__(256) k_inst(uint64_t* out, uint32_t seed) {
             if (KIND == 7) { uint32_t t = (uint32_t)a[c]; asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(t) : "v"(x)); a[c] = t; }
             if (KIND == 8) { uint32_t t = (uint32_t)a[c]; asm volatile("v_add_u32 %0, %0, %1" : "+v"(t) : "v"(x)); a[c] = t; }
             if (KIND == 9) { uint32_t t = (uint32_t)a[c]; asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(t) : "v"(x)); a[c] = t; }
+            // mixes: does a cheap instruction issue in the shadow of the multiplier?  (ops counted = the mads only)
+            if (KIND == 10) { asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[c]) : "v"(x), "v"(y) : "s10", "s11");
+                              uint32_t t = (uint32_t)d[c]; asm volatile("v_and_b32 %0, %0, %1" : "+v"(t) : "v"(x)); d[c] = t; }
+            if (KIND == 11) { asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[c]) : "v"(x), "v"(y) : "s10", "s11");
+                              asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(b[c])); }
+            if (KIND == 12) { asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[c]) : "v"(x), "v"(y) : "s10", "s11");
+                              asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(b[c]) : "v"(b[(c + 1) % CHAINS])); }
+            if (KIND == 13) { asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[c]) : "v"(x), "v"(y) : "s10", "s11");
+                              uint32_t t = (uint32_t)d[c], u = (uint32_t)b[c];
+                              asm volatile("v_and_b32 %0, %0, %1" : "+v"(t) : "v"(x)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(u) : "v"(x));
+                              d[c] = t; b[c] = u; }
         }
     }
     uint64_t s = 0;
 #pragma unroll
-    for (int c = 0; c < CHAINS; c++) s += a[c] + (uint64_t)d[c];
+    for (int c = 0; c < CHAINS; c++) s += a[c] + b[c] + (uint64_t)d[c];
     if (s == 0x1234567) out[0] = s;
 }
 
@@ -86,6 +97,39 @@ __global__ void __launch_bounds__(128, 2) k_xyzz(uint32_t* out, uint32_t seed, i
     if (xa.X.l[0] == 0x3fffffff && xa.Y.l[1] == 0x12345) out[0] = xa.ZZ.l[2];
 }
 
+// the same step through the lazy formula (ec.hpp xyzz_madd_lazy): what k_fixed_msm runs
+template <class C>
+__global__ void __launch_bounds__(128, 2) k_xyzz_lazy(uint32_t* out, uint32_t seed, int iters) {
+    Aff<C> g = aff_generator<C>();
+    uint32_t kw[1] = {seed + threadIdx.x + 2};
+    Aff<C> p = jac_to_aff(aff_mul_words(g, kw, 1));
+    fe_cond_sub_p(p.x);
+    fe_cond_sub_p(p.y);
+    Xyzz<C> xa = xyzz_madd(xyzz_dbl_aff(g), g);
+    for (int it = 0; it < iters; it++) xyzz_madd_lazy(xa, p, (it & 1) != 0);
+    if (xa.X.l[0] == 0x3fffffff && xa.Y.l[1] == 0x12345) out[0] = xa.ZZ.l[2];
+}
+
+// one dependent v_mad_u64_u32 chain per wave, NCH independent chains: issue-to-issue latency of the multiplier
+template <int NCH>
+__global__ void __launch_bounds__(64) k_mad_lat(uint64_t* out, uint32_t seed) {
+    uint64_t a[NCH];
+    uint32_t x = seed + threadIdx.x, y = seed * 3 + 7;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) a[c] = seed + c;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+                asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(a[c]) : "v"(x), "v"(y) : "s10", "s11");
+    }
+    uint64_t s = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) s += a[c];
+    if (s == 0x1234567) out[0] = s;
+}
+
 template <class F>
 static double time_ms(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -109,7 +153,8 @@ int main() {
     CK(hipMalloc(&dout, 4096));
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d,\n", prop.name, cus, prop.clockRate / 1000);
     const char* names[] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_and_b32", "v_mul_lo_u32", "v_fma_f64", "v_mad_u32_u24",
-                           "v_lshrrev_b64", "v_mul_hi_u32", "v_add_u32", "v_add3_u32"};
+                           "v_lshrrev_b64", "v_mul_hi_u32", "v_add_u32", "v_add3_u32", "mad_with_and_1to1", "mad_with_lshrrev_b64_1to1",
+                           "mad_with_lshl_add_u64_1to1", "mad_with_and_add_1to2"};
     // 8 waves per SIMD: 256-thread blocks, 8 per CU
     const int grid = cus * 8;
     auto inst = [&](int kind, auto kern) {
@@ -120,6 +165,15 @@ int main() {
     };
     inst(0, k_inst<0>); inst(1, k_inst<1>); inst(2, k_inst<2>); inst(3, k_inst<3>); inst(4, k_inst<4>);
     inst(5, k_inst<5>); inst(6, k_inst<6>); inst(7, k_inst<7>); inst(8, k_inst<8>); inst(9, k_inst<9>);
+    inst(10, k_inst<10>); inst(11, k_inst<11>); inst(12, k_inst<12>); inst(13, k_inst<13>);
+    // dependent multiplier chains, ONE wave per SIMD (4 waves of 64 threads per CU): cycles between dependent issues
+    auto lat = [&](const char* name, auto kern, int nch) {
+        const int g = cus * 4;
+        double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(g), dim3(64), 0, 0, dout, 12345u); }, 3);
+        double per_wave = (double)ITERS * 8 * nch;                      // mads issued by one wave
+        printf(" \"%s\": {\"clk_per_mad_one_wave_per_simd\": %.2f},\n", name, ms * 1e-3 * prop.clockRate * 1e3 / per_wave);
+    };
+    lat("mad_chain_1", k_mad_lat<1>, 1); lat("mad_chain_2", k_mad_lat<2>, 2); lat("mad_chain_4", k_mad_lat<4>, 4);
 
     uint32_t* o32 = reinterpret_cast<uint32_t*>(dout);
     auto fld = [&](const char* name, auto kern, int iters, int block, int blocks_per_cu) {
@@ -150,6 +204,8 @@ int main() {
     grp("jac_add_bls", k_group<Bls12381, 2>, 300, 8);
     grp("xyzz_madd_bls", k_xyzz<Bls12381>, 300, 8);
     grp("xyzz_madd_secp", k_xyzz<Secp256k1>, 300, 8);
+    grp("xyzz_madd_lazy_bls", k_xyzz_lazy<Bls12381>, 300, 8);
+    grp("xyzz_madd_lazy_secp", k_xyzz_lazy<Secp256k1>, 300, 8);
     grp("jac_madd_secp", k_group<Secp256k1, 0>, 300, 8);
     grp("jac_dbl_secp", k_group<Secp256k1, 1>, 300, 8);
     printf(" \"end\": 0}\n");
