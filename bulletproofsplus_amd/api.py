@@ -441,15 +441,33 @@ def _verifier_combined_workspace_bytes(self, count: int) -> int:
     return _lib.lib().bpp_verifier_combined_workspace_bytes(self.handle, count)
 
 
-def _verifier_run_combined_device(self, d_points: int, d_scalars: int, count: int, seed: int, d_out_partial: int,
-                                  d_ok: int, d_workspace: int, workspace_bytes: int, stream: int = 0,
-                                  d_challenges: int = 0):
+def _verifier_run_combined_device(self, d_points: int, d_scalars: int, count: int, weight_key, index_base: int,
+                                  d_out_partial: int, d_ok: int, d_workspace: int, workspace_bytes: int, stream: int = 0,
+                                  d_challenges: int = 0, d_weights: int = 0):
     """Combined batch check (NOT the reference's per-proof semantics, see include/bpp_amd.h): one weighted
-    sum of the batch's verification MulVecs.  d_ok[0] == 0 iff it is the identity."""
-    check(_lib.lib().bpp_verifier_run_combined(self.handle, d_points, d_scalars, count, d_challenges or None,
-                                               ctypes.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), d_out_partial, d_ok,
+    sum of the batch's verification MulVecs.  d_ok[0] == 0 iff it is the identity.
+    weight_key: 32 secret bytes (None = drawn here from os.urandom, fresh per call) expanded on the device by a
+    SHA-256 PRF over the global proof index index_base + p; or d_weights: count x 16 bytes on the device."""
+    if d_weights:
+        key = None
+    else:
+        if weight_key is None:
+            import os
+            weight_key = os.urandom(32)
+        key = bytes(weight_key)
+        if len(key) != 32:
+            raise ValueError("weight_key must be 32 bytes")
+    check(_lib.lib().bpp_verifier_run_combined(self.handle, d_points, d_scalars, count, d_challenges or None, key,
+                                               ctypes.c_uint64(index_base), d_weights or None, d_out_partial, d_ok,
                                                d_workspace, workspace_bytes, stream or None),
           "bpp_verifier_run_combined")
+
+
+def _verifier_derive_challenges_device(self, d_points: int, count: int, d_challenges: int, stream: int = 0):
+    """Fiat-Shamir challenges [y, z, e, e_1..e_k] of every proof record of a resident batch (csrc/transcript.hpp),
+    in the layout run_device takes as d_challenges.  The reference has no transcript: parity unpinned."""
+    check(_lib.lib().bpp_verifier_derive_challenges(self.handle, d_points, count, d_challenges, stream or None),
+          "bpp_verifier_derive_challenges")
 
 
 def _verifier_sum_partials_device(self, d_partials: int, n: int, d_ok: int, stream: int = 0):
@@ -498,6 +516,7 @@ BatchVerifier.prove_batch_device = _engine_prove_batch_device
 BatchVerifier.partial_bytes = _verifier_partial_bytes
 BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device
+BatchVerifier.derive_challenges_device = _verifier_derive_challenges_device
 BatchVerifier.sum_partials_device = _verifier_sum_partials_device
 BatchVerifier.set_profiling = _verifier_set_profiling
 BatchVerifier.profile = _verifier_profile

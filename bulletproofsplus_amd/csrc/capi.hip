@@ -180,7 +180,7 @@ extern "C" size_t bpp_verifier_partial_bytes(const bpp_verifier* v) {
     if (!v) return 0;
     size_t r = 0;
     dispatch(v->ctx.curve, [&](auto cv) -> int {
-        r = (size_t)jac_words<decltype(cv)>() * 4;
+        r = (size_t)partial_words<decltype(cv)>() * 4;
         return 0;
     });
     return r;
@@ -195,15 +195,16 @@ extern "C" size_t bpp_verifier_combined_workspace_bytes(const bpp_verifier* v, s
     return r;
 }
 extern "C" int bpp_verifier_run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars,
-                                         size_t count, const uint64_t* d_challenges, uint64_t seed,
-                                         void* d_out_partial, uint32_t* d_ok, void* d_workspace,
-                                         size_t workspace_bytes, void* stream) {
+                                         size_t count, const uint64_t* d_challenges, const uint8_t* weight_key,
+                                         uint64_t index_base, const uint64_t* d_weights, void* d_out_partial,
+                                         uint32_t* d_ok, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!v || !d_points || !d_scalars || !d_out_partial || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
+    if (!weight_key && !d_weights) return fail(BPP_E_ARG, "the combined check needs a weight key or a weight buffer");
     if (count == 0) return fail(BPP_E_ARG, "empty batch");
     HIPCHK(hipSetDevice(v->ctx.device));
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
-        return VerifyImpl<decltype(cv)>::run_combined(v, d_points, d_scalars, count, d_challenges, seed,
-                                                      static_cast<uint32_t*>(d_out_partial), d_ok, d_workspace,
+        return VerifyImpl<decltype(cv)>::run_combined(v, d_points, d_scalars, count, d_challenges, weight_key, index_base,
+                                                      d_weights, static_cast<uint32_t*>(d_out_partial), d_ok, d_workspace,
                                                       workspace_bytes, static_cast<hipStream_t>(stream));
     });
 }
@@ -214,6 +215,17 @@ extern "C" int bpp_verifier_sum_partials(bpp_verifier* v, const void* d_partials
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::sum_partials(static_cast<const uint32_t*>(d_partials), n, d_ok,
                                                       static_cast<hipStream_t>(stream));
+    });
+}
+
+extern "C" int bpp_verifier_derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count,
+                                              uint64_t* d_challenges, void* stream) {
+    if (!v || !d_points || !d_challenges) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::derive_challenges(v, d_points, count, d_challenges,
+                                                           static_cast<hipStream_t>(stream));
     });
 }
 

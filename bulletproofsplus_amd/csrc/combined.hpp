@@ -3,7 +3,10 @@
 // Not a reference code path: the reference verifies one proof at a time (src/range/mod.rs:57-78) and has no
 // batch API.  For a batch of proofs p = 1..B with verification MulVecs  M_p = sum_t s_{p,t} * P_{p,t}
 // (each must be the identity), this mode checks the single equation   sum_p w_p * M_p == identity
-// with weights w_p from a stated deterministic stream (SplitMix64 of (seed, p), 128 bit, odd):
+// with 128-bit weights w_p that the proofs' author must not be able to predict: either supplied by the caller
+// (count x 16 bytes, e.g. drawn from a transcript over the whole batch) or expanded on the device from a 256-bit
+// secret key, w_p = SHA-256(key || "bppw" || global proof index)[0..16) -- a PRF whose domain is the GLOBAL index,
+// so ranks sharing one key never reuse a weight:
 //   * the 2mn+2 fixed generators are shared by every proof, so their terms collapse to ONE fixed-base
 //     MulVec with scalars S_f = sum_p w_p * s_{p,f}               (k_comb_fixed, then k_fixed_msm, count 1)
 //   * the proof-carried points form ONE variable-base MulVec of B * (3+2k+m) terms with scalars
@@ -11,30 +14,60 @@
 //     (k_var_digits / k_var_tables / k_var_windows): the 65 window sums of every proof are added ACROSS proofs,
 //     window by window (k_comb_window_fold), and ONE Horner lane -- riding in the fixed-generator launch --
 //     finishes the sum.  (A 300 k-point bucket MSM took 17 ms per 8192 proofs here; this takes ~5 ms + the Horner.)
-// All-valid batches always pass; a batch with an invalid proof fails except with probability ~2^-128 over
-// the weights, and the caller then falls back to the per-proof path (bpp_verifier_run) for exact verdicts.
-// Across GPUs each rank produces one jacobian partial; they are exchanged once and summed
-// (k_comb_sum_partials) -- the "single reduce over xGMI" of the north star.
+// All-valid batches always pass; a batch with an invalid proof fails except with probability ~2^-128 PROVIDED the
+// weights were unpredictable when the proofs were made (a fixed or guessable key gives no such bound: two invalid
+// proofs can be built to cancel), and the caller then falls back to the per-proof path (bpp_verifier_run) for
+// exact verdicts.  The check assumes proof points in the prime-order subgroup (the serialized-proof path checks
+// it, container.hpp); a small-order component can vanish under an unlucky weight.
+// Across GPUs each rank produces one partial -- its jacobian sum plus a validity word (set when any of its
+// proofs carried an invalid point) -- they are exchanged once and summed / OR-ed (k_comb_sum_partials): the
+// "single reduce over xGMI" of the north star.
 #pragma once
 #include "kernels.hpp"
+#include "sha256.hpp"
 
 namespace bpp {
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
+// words of one partial: the jacobian image followed by 4 words [invalid-point flag, 0, 0, 0]
+template <class C>
+constexpr int partial_words() {
+    return jac_words<C>() + 4;
 }
 
-// weights[p]: Montgomery form, packed 8 words.  w_p = (splitmix64(seed + 2p) | 1) + 2^64 * splitmix64(seed + 2p + 1)
+// weights[p]: Montgomery form, packed 8 words.  raw != null: w_p = raw[p] (16 bytes, little-endian);
+// else w_p = SHA-256(key[32] || "bppw" || (index_base + p) as u64 LE)[0..16) read little-endian.  0 -> 1.
+struct WeightKey {
+    uint32_t w[8];   // the 32 key bytes as little-endian words
+};
 template <class C>
-__global__ void __launch_bounds__(256) k_comb_weights(uint64_t seed, uint32_t* __restrict__ weights, size_t count) {
+__global__ void __launch_bounds__(256) k_comb_weights(WeightKey key, uint64_t index_base,
+                                                      const uint32_t* __restrict__ raw, uint32_t* __restrict__ weights,
+                                                      size_t count) {
     using P = typename C::Fr;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= count) return;
-    const uint64_t lo = splitmix64(seed + 2 * p) | 1ull, hi = splitmix64(seed + 2 * p + 1);
-    uint32_t w[8] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), 0, 0, 0, 0};
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (raw) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) w[i] = raw[p * 4 + i];
+    } else {
+        Sha256 s;
+        sha256_init(s);
+#pragma unroll
+        for (int i = 0; i < 8; i++) sha256_word_le(s, key.w[i]);
+        sha256_word_le(s, 0x77707062u);   // "bppw"
+        const uint64_t idx = index_base + p;
+        sha256_word_le(s, (uint32_t)idx);
+        sha256_word_le(s, (uint32_t)(idx >> 32));
+        uint32_t dg[8];
+        sha256_final(s, dg);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t be = dg[i];
+            w[i] = (be >> 24) | ((be >> 8) & 0xff00u) | ((be << 8) & 0xff0000u) | (be << 24);
+        }
+    }
+    if ((w[0] | w[1] | w[2] | w[3]) == 0) w[0] = 1;
     Fe<P> x = fe_from_canonical<P>(w);
     uint32_t o[8];
     fe_store(x, o);
@@ -121,13 +154,18 @@ __global__ void __launch_bounds__(256) k_comb_verdict(const uint32_t* __restrict
     if (threadIdx.x == 0) {
         Jac<C> acc = jac_ldg<C>(partial + threadIdx.x);
         ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
+        uint32_t* flag = const_cast<uint32_t*>(partial) + jac_words<C>();   // travels with the partial to the other ranks
+        flag[0] = anybad ? 1u : 0u;
+        flag[1] = flag[2] = flag[3] = 0u;
     }
 }
 
-// sum of n jacobian partials (one per rank) -> verdict (and the sum itself, optional)
+// sum of n partials, `stride` words apart -> verdict (and the sum itself, optional).  with_flags: every partial is
+// followed by its validity word (the cross-rank form); the verdict then also requires every flag to be clear.
 template <class C>
-__global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __restrict__ partials, uint32_t n,
-                                                          uint32_t* __restrict__ ok, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __restrict__ partials, uint32_t n, uint32_t stride,
+                                                          uint32_t with_flags, uint32_t* __restrict__ ok,
+                                                          uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -135,8 +173,12 @@ __global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __rest
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     partials += lane_zero;
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t t = 0; t < n; t++) acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * JW));
-    ok[0] = acc.is_inf() ? 0u : 1u;
+    uint32_t anybad = 0;
+    for (uint32_t t = 0; t < n; t++) {
+        acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * stride));
+        if (with_flags) anybad |= partials[(size_t)t * stride + JW];
+    }
+    ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
     if (out) jac_stg<C>(out, acc);
 }
 

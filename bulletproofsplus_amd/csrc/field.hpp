@@ -25,8 +25,11 @@
 
 #if defined(__HIPCC__)
 #define BPP_HD __host__ __device__ __forceinline__
+// cold, bulky helpers (the hash): a real call on the device keeps kernels that use them many times at a sane size
+#define BPP_HD_NOINLINE inline __host__ __device__ __noinline__
 #else
 #define BPP_HD inline
+#define BPP_HD_NOINLINE inline
 #endif
 
 namespace bpp {

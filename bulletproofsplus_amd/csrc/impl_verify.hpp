@@ -16,6 +16,7 @@ struct bpp_verifier {
     bpp::VerifyShape s;
     bpp::DevBuf table;       // window tables
     bpp::DevBuf challenges;  // default challenges
+    bpp::TranscriptState tr0;   // transcript state after the domain, curve, (n, m) and generator digest
     size_t table_bytes = 0;
     // optional per-stage HIP-event timing: one (begin, end) event pair per stage and remembered pass
     bool profiling = false;
@@ -142,6 +143,7 @@ struct VerifyImpl {
             hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, s, v->table.u32(),
                                tbl_scratch.u32(), f0, f1);
         }
+        tr_initial_state(C::ID, s.n, s.m, reinterpret_cast<const uint32_t*>(fixed.data()), fixed.size() * 2, v->tr0.st);
         std::vector<uint32_t> ch;
         default_challenges(s, ch);
         e = v->challenges.alloc(ch.size() * 4);
@@ -236,6 +238,14 @@ struct VerifyImpl {
         return BPP_OK;
     }
 
+    static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
+                                 hipStream_t st) {
+        hipLaunchKernelGGL(k_transcript_challenges<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, v->s, v->tr0,
+                           reinterpret_cast<const uint32_t*>(d_points), reinterpret_cast<uint32_t*>(d_challenges), count);
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
         size_t pts, bad, scalars, weights, comb_sc, fpart, var_sc, vdig, vtbl, vscr, vwsum, vfold, total;
@@ -278,8 +288,9 @@ struct VerifyImpl {
 
     // d_out_partial: one jacobian (3N words, opaque to the caller) = this batch's weighted sum
     static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
-                            const uint64_t* d_challenges, uint64_t seed, uint32_t* d_out_partial, uint32_t* d_ok,
-                            void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+                            const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                            const uint64_t* d_weights, uint32_t* d_out_partial, uint32_t* d_ok, void* d_workspace,
+                            size_t workspace_bytes, hipStream_t st) {
         const VerifyShape& s = v->s;
         const CombLayout L = comb_layout(s, count);
         if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
@@ -306,7 +317,13 @@ struct VerifyImpl {
         const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
         hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
                            reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
-        hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, seed, w_wt, count);
+        WeightKey wk;
+        for (int i = 0; i < 8; i++)
+            wk.w[i] = d_weights ? 0u
+                                : (uint32_t)weight_key[4 * i] | ((uint32_t)weight_key[4 * i + 1] << 8) |
+                                      ((uint32_t)weight_key[4 * i + 2] << 16) | ((uint32_t)weight_key[4 * i + 3] << 24);
+        hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, wk, index_base,
+                           reinterpret_cast<const uint32_t*>(d_weights), w_wt, count);
         hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
         // proof-carried points: weighted scalars -> per-proof Straus window sums -> summed across proofs per window
         hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
@@ -328,7 +345,8 @@ struct VerifyImpl {
         // leading block; the Horner result lands behind the block sums
         hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
                            v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u);
-        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, d_ok, d_out_partial);
+        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
+                           d_out_partial);
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
         HIPCHK(hipGetLastError());
         return BPP_OK;
@@ -450,9 +468,10 @@ struct VerifyImpl {
         return BPP_OK;
     }
 
+    // d_partials: n partials as bpp_verifier_run_combined wrote them (jacobian + validity word each)
     static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
-        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n, d_ok,
-                           (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n,
+                           (uint32_t)partial_words<C>(), 1u, d_ok, (uint32_t*)nullptr);
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }

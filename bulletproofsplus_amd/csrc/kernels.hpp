@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include "ec.hpp"
 #include "ed25519.hpp"
+#include "transcript.hpp"
 
 namespace bpp {
 
@@ -553,6 +554,21 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
         fe_to_canonical(he, wv);
         st_words<8>(o + (size_t)(5 + 2 * k + mn + i) * 8, wv);
     }
+}
+
+// ---- Fiat-Shamir challenges (transcript.hpp) --------------------------------------------------------------
+struct TranscriptState {
+    uint32_t st[8];
+};
+// one lane per proof: record -> [y, z, e, e_1..e_k]
+template <class C>
+__global__ void __launch_bounds__(64) k_transcript_challenges(VerifyShape s, TranscriptState st0,
+                                                              const uint32_t* __restrict__ records,
+                                                              uint32_t* __restrict__ challenges, size_t count) {
+    constexpr uint32_t WW = 2 * C::Fp::N + 2;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    tr_verifier_challenges<C>(st0.st, records + b * (size_t)s.NV * WW, s.k, s.m, s.mn, challenges + b * (size_t)(3 + s.k) * 8);
 }
 
 // ---- window tables -------------------------------------------------------------------------------------

@@ -160,20 +160,45 @@ int bpp_range_prove_batch_device(bpp_verifier *engine, const uint64_t *d_v, cons
                                  void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- combined batch check ("final multiscalar check") -- an engine mode, NOT a reference code path ----
- * One random linear combination of the batch's verification MulVecs, sum_p w_p * M_p == identity, with
- * w_p = 128-bit odd values from SplitMix64(seed, p) (csrc/combined.hpp): the fixed generators collapse
- * to one fixed-base MulVec, the proof-carried points form one bucket-method MulVec.  An all-valid batch
- * always passes; a batch holding an invalid proof fails except with probability ~2^-128 over the weights,
- * and the caller then runs bpp_verifier_run for the exact per-proof verdicts of the reference.
- *   d_out_partial: bpp_verifier_partial_bytes() bytes -- this call's weighted sum (opaque jacobian image);
- *                  ranks exchange these once (RCCL all-gather) and bpp_verifier_sum_partials adds them
+ * One random linear combination of the batch's verification MulVecs, sum_p w_p * M_p == identity, with 128-bit
+ * weights w_p (csrc/combined.hpp): the fixed generators collapse to one fixed-base MulVec, the proof-carried
+ * points run through the verifier's Straus kernels and are summed window by window.  An all-valid batch always
+ * passes.  A batch holding an invalid proof fails except with probability ~2^-128 -- PROVIDED the weights could not
+ * be predicted by whoever made the proofs; with a fixed or guessable key two invalid proofs can be made to cancel.
+ * So the weights come from the caller, one of
+ *   d_weights  : count x 16 bytes on the device (little-endian 128-bit values), e.g. from a transcript over the
+ *                whole batch; or
+ *   weight_key : 32 secret bytes (host pointer) from the OS CSPRNG, fresh per call or per verifier; the device
+ *                expands w_p = SHA-256(key || "bppw" || (index_base + p) as u64)[0..16).  index_base is the GLOBAL index
+ *                of this call's first proof, so ranks that share a key never share a weight.
+ * The caller falls back to bpp_verifier_run for the exact per-proof verdicts of the reference when the check fails.
+ * It assumes proof points of the prime-order subgroup (bpp_proofs_decode checks that for serialized proofs).
+ *   d_out_partial: bpp_verifier_partial_bytes() bytes -- this call's weighted sum (opaque jacobian image) followed by
+ *                  a validity word (non-zero when a proof of this call carried an invalid point); ranks exchange
+ *                  these once (RCCL all-gather) and bpp_verifier_sum_partials adds the sums and ORs the words
  *   d_ok         : one uint32_t, 0 iff the partial is the identity and every proof point was valid */
 size_t bpp_verifier_partial_bytes(const bpp_verifier *v);
 size_t bpp_verifier_combined_workspace_bytes(const bpp_verifier *v, size_t count);
 int bpp_verifier_run_combined(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
-                              const uint64_t *d_challenges, uint64_t seed, void *d_out_partial, uint32_t *d_ok,
-                              void *d_workspace, size_t workspace_bytes, void *stream);
+                              const uint64_t *d_challenges, const uint8_t *weight_key, uint64_t index_base,
+                              const uint64_t *d_weights, void *d_out_partial, uint32_t *d_ok, void *d_workspace,
+                              size_t workspace_bytes, void *stream);
+/* d_partials: n partials of bpp_verifier_partial_bytes() bytes each; d_ok = 0 iff their sum is the identity and no
+ * rank reported an invalid point */
 int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n, uint32_t *d_ok, void *stream);
+
+/* ---- Fiat-Shamir transcript (csrc/transcript.hpp) -- what the reference's constants stand in for --------
+ * The reference has no transcript (every challenge is a literal, src/range/mod.rs:278-279,
+ * :417-418, src/weighted_inner_product_proof.rs:131, :211, :353, :369; the intended labels survive as a comment at
+ * src/weighted_inner_product_proof.rs:339-348).  PARITY UNPINNED: pinned by oracle/pyref.py and the C oracle.
+ * bpp_verifier_derive_challenges hashes each proof record of a resident batch (SHA-256, one lane per proof) into the
+ * block [y, z, e, e_1..e_k] that bpp_verifier_run / bpp_verifier_run_combined accept as d_challenges:
+ *   d_points     : count x (3 + 2k + m) wire points, as for bpp_verifier_run
+ *   d_challenges : count x (3 + k) scalars (out)
+ * bpp_range_prove_batch_fs is the prover under the same transcript (round t + 1 waits for L_t, R_t); outputs as
+ * bpp_range_prove_batch_device. */
+int bpp_verifier_derive_challenges(bpp_verifier *v, const uint64_t *d_points, size_t count, uint64_t *d_challenges,
+                                   void *stream);
 
 /* Per-stage timing with HIP events recorded on the caller's stream around the kernels of a pass
  * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant; its first blocks also run

@@ -223,7 +223,7 @@ def range_prove(pk: PublicKey, n: int, values, gammas, V=None, faithful_timing=F
 
 
 def range_verify(pk: PublicKey, n: int, m: int, proof_points, proof_scalars, V,
-                 want_scalars=False, want_result=False, skip_msm=False, pippenger_window=0):
+                 want_scalars=False, want_result=False, skip_msm=False, pippenger_window=0, want_challenges=False):
     """RangeProof::verify.  Returns rc (0 Ok / 1 VerificationError) or a tuple with the extras.
     pippenger_window in 2..16: the final MulVec by the bucket method instead of the reference's naive loop
     (same point; bench.py's "CPU-Pippenger" baseline)."""
@@ -238,11 +238,27 @@ def range_verify(pk: PublicKey, n: int, m: int, proof_points, proof_scalars, V,
     res = np.zeros(PW, dtype=np.uint64) if want_result else None
     G = np.ascontiguousarray(pk.G)
     H = np.ascontiguousarray(pk.H)
-    rc = lib().orc_range_verify(curve, _p(pk.gh), _p(G), _p(H), ctypes.c_size_t(n), ctypes.c_size_t(m),
-                                _p(proof_points), ctypes.c_size_t(k), _p(proof_scalars), _p(V),
-                                _p(sc) if sc is not None else None,
-                                _p(res) if res is not None else None,
-                                1 if skip_msm else (int(pippenger_window) if 2 <= int(pippenger_window) <= 16 else 0))
+    ch = np.zeros((3 + k, 4), dtype=np.uint64) if want_challenges else None
+    rc = lib().orc_range_verify_fs(curve, _p(pk.gh), _p(G), _p(H), ctypes.c_size_t(n), ctypes.c_size_t(m),
+                                   _p(proof_points), ctypes.c_size_t(k), _p(proof_scalars), _p(V),
+                                   _p(sc) if sc is not None else None,
+                                   _p(res) if res is not None else None,
+                                   1 if skip_msm else (int(pippenger_window) if 2 <= int(pippenger_window) <= 16 else 0),
+                                   _p(ch) if ch is not None else None)
+    if want_challenges:
+        return rc, sc, res, ch
     if not want_scalars and not want_result:
         return rc
     return rc, sc, res
+
+
+def set_transcript(on: bool):
+    """Transcript mode of the C oracle (csrc/transcript.hpp restated; the reference has none): prove and verify draw
+    their challenges from the SHA-256 transcript instead of the reference's literals.  Global; reset after use."""
+    lib().orc_set_transcript(1 if on else 0)
+
+
+def sha256(data: bytes) -> bytes:
+    out = ctypes.create_string_buffer(32)
+    lib().orc_sha256(data, ctypes.c_size_t(len(data)), out)
+    return out.raw

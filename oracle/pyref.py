@@ -424,9 +424,101 @@ class Transcript:
     R, S, DELTA, ETA = 33, 44, 88, 123   # wip.rs:175-178
     E_FINAL = 99          # wip.rs:211, :369
 
+    # Fiat-Shamir mode (csrc/transcript.hpp; the reference has none): `fs` holds an FsTranscript factory, `run` the
+    # running transcript of the proof being made, `cached` the challenges a verifier derived from a proof.
+    fs = None
+    run = None
+    cached = None
+
     @classmethod
     def e_round(cls, i):
+        if cls.cached is not None:
+            return cls.cached["e_rounds"][i]
         return cls.E_ROUND[i] if isinstance(cls.E_ROUND, (list, tuple)) else cls.E_ROUND
+
+    @classmethod
+    def e_final(cls):
+        return cls.cached["e"] if cls.cached is not None else cls.E_FINAL
+
+    @classmethod
+    def yz(cls, m):
+        if cls.cached is not None:
+            return cls.cached["y"], cls.cached["z"]
+        return (cls.Y_SINGLE, cls.Z_SINGLE) if m == 1 else (cls.Y_MULTI, cls.Z_MULTI)
+
+
+class FsTranscript:
+    """The SHA-256 transcript of bulletproofsplus_amd/csrc/transcript.hpp, restated with hashlib (TEST ORACLE for it).
+    st0 = SHA-256(domain || curve id, n, m as u32 LE || SHA-256(pk wire bytes)); append / challenge as documented
+    there.  Points enter as the (2L+1) x u64 little-endian wire words of include/bpp_amd.h."""
+
+    DOMAIN = b"BulletproofsPlus-AMD transcript v1\0\0"
+
+    def __init__(self, curve: dict, curve_id: int, n: int, m: int, pk):
+        import hashlib
+        self.h = hashlib.sha256
+        self.curve = curve
+        self.L = curve["fp_bytes"] // 8
+        self.r = curve["r"]
+        pkb = b"".join(self.point_bytes(P) for P in [pk.g, pk.h] + list(pk.G_vec) + list(pk.H_vec))
+        hdr = self.DOMAIN + curve_id.to_bytes(4, "little") + n.to_bytes(4, "little") + m.to_bytes(4, "little")
+        self.st0 = self.h(hdr + self.h(pkb).digest()).digest()
+        self.st = self.st0
+
+    def start(self):
+        self.st = self.st0
+        return self
+
+    def point_bytes(self, P) -> bytes:
+        nb = 8 * self.L
+        if P is None or (self.curve["name"] == "ed25519" and P == (0, 1)):
+            return bytes(2 * nb) + (1).to_bytes(8, "little")
+        return P[0].to_bytes(nb, "little") + P[1].to_bytes(nb, "little") + bytes(8)
+
+    def append(self, tag: bytes, data: bytes):
+        self.st = self.h(self.st + tag.ljust(4, b"\0") + len(data).to_bytes(4, "little") + data).digest()
+
+    def append_point(self, tag: bytes, P):
+        self.append(tag, self.point_bytes(P))
+
+    def challenge(self, tag: bytes) -> int:
+        t4 = tag.ljust(4, b"\0")
+        c0 = self.h(self.st + t4 + (0x80000000).to_bytes(4, "little")).digest()
+        c1 = self.h(self.st + t4 + (0x80000001).to_bytes(4, "little")).digest()
+        self.st = self.h(self.st + t4 + (0x80000002).to_bytes(4, "little")).digest()
+        x = (int.from_bytes(c0, "little") + (int.from_bytes(c1, "little") << 256)) % self.r
+        return x or 1
+
+    # ---- the protocol's sequence -----------------------------------------------------------
+    def yz(self, V_list, A):
+        for V in V_list:
+            self.append_point(b"V", V)
+        self.append_point(b"A", A)
+        return self.challenge(b"y"), self.challenge(b"z")
+
+    def wip_start(self, mn: int):
+        self.append(b"dsep", b"wipp v1\0")
+        self.append(b"n", mn.to_bytes(8, "little"))
+
+    def round(self, L, R) -> int:
+        self.append_point(b"L", L)
+        self.append_point(b"R", R)
+        return self.challenge(b"e")
+
+    def final(self, A, B) -> int:
+        self.append_point(b"wA", A)
+        self.append_point(b"wB", B)
+        return self.challenge(b"e")
+
+    def verifier_challenges(self, proof, commitment_vec):
+        """[y, z, e, e_1..e_k] for a RangeProof, as bpp_verifier_derive_challenges computes them"""
+        self.start()
+        y, z = self.yz(list(commitment_vec), proof.A)
+        w = proof.proof
+        self.wip_start(1 << len(w.L_vec))
+        es = [self.round(L, R) for L, R in zip(w.L_vec, w.R_vec)]
+        e = self.final(w.A, w.B)
+        return dict(y=y, z=z, e=e, e_rounds=es)
 
 
 # --------------------------------------------------------------------------------------
@@ -454,6 +546,8 @@ class WeightedInnerProductProof:
         n = len(G)
         assert len(H) == n and len(a) == n and len(b) == n and len(pw) == n
         assert n & (n - 1) == 0 and n > 0
+        if T.run is not None:
+            T.run.wip_start(n)
         L_vec, R_vec = [], []
         while n != 1:
             n //= 2
@@ -481,7 +575,7 @@ class WeightedInnerProductProof:
             L_vec.append(L)
             R_vec.append(R)
 
-            e = F.new(T.e_round(len(L_vec) - 1))
+            e = T.run.round(L, R) if T.run is not None else F.new(T.e_round(len(L_vec) - 1))
             e_inv = F.inv(e)
             e_sqr = e * e % r
             e_sqr_inv = e_inv * e_inv % r
@@ -517,7 +611,7 @@ class WeightedInnerProductProof:
         mv.add_scalar(rcs); mv.add_scalar(eta)
         mv.add_point(pk.g); mv.add_point(pk.h)
         B = mv.calculate()
-        e = F.new(T.E_FINAL)
+        e = T.run.final(A, B) if T.run is not None else F.new(T.E_FINAL)
         r_prime = (rr + a[0] * e) % r
         s_prime = (s + b[0] * e) % r
         d_prime = (eta + delta * e + alpha * e * e) % r
@@ -534,7 +628,7 @@ class WeightedInnerProductProof:
         allinv, challenges_inv = F.batch_invert(challenges)
         challenges_sqr = [c * c % r for c in challenges]
         challenges_inv_sqr = [c * c % r for c in challenges_inv]
-        e = F.new(Transcript.E_FINAL)
+        e = F.new(Transcript.e_final())
         s_vec = [allinv]
         for i in range(1, n):
             log_i = i.bit_length() - 1
@@ -595,6 +689,8 @@ class RangeProof:
     def prove(pk: PublicKey, n: int, prover: RangeProver, trace=None):
         # range/mod.rs:31-55
         m = len(prover.v_vec)
+        Transcript.cached = None
+        Transcript.run = Transcript.fs.start() if Transcript.fs is not None else None
         if m == 1:
             return RangeProof._prove_single(pk, n, prover.v_vec[0], prover.gamma_vec[0],
                                             prover.commitment_vec[0], trace)
@@ -617,7 +713,10 @@ class RangeProof:
             v_bits.append(bit)
             pt = pk.G_vec[i] if bit else G_.neg(pk.H_vec[i])
             A = G_.add(A, pt)
-        y, z = F.new(T.Y_SINGLE), F.new(T.Z_SINGLE)
+        if T.run is not None:
+            y, z = T.run.yz([commitment], A)
+        else:
+            y, z = F.new(T.Y_SINGLE), F.new(T.Z_SINGLE)
         one, two = 1, 2
         power_of_two = F.exp_iter_type1(2, n)
         power_of_y = F.exp_iter_type2(y, n)
@@ -667,7 +766,10 @@ class RangeProof:
             v_bits.append(bit)
             pt = pk.G_vec[i] if bit else G_.neg(pk.H_vec[i])
             A = G_.add(A, pt)
-        y, z = F.new(T.Y_MULTI), F.new(T.Z_MULTI)
+        if T.run is not None:
+            y, z = T.run.yz(list(commitment_vec), A)
+        else:
+            y, z = F.new(T.Y_MULTI), F.new(T.Z_MULTI)
         power_of_two = F.exp_iter_type1(2, n)
         power_of_y = F.exp_iter_type2(y, mn)
         power_of_y_rev = power_of_y[::-1]
@@ -712,9 +814,15 @@ class RangeProof:
         """Returns the final MulVec of range/mod.rs:480-501 (m>1) or wip.rs:297-318 (m==1),
         or None when verification_scalars takes its error branch."""
         m = len(commitment_vec)
-        if m == 1:
-            return self._verify_single_mv(pk, n, commitment_vec[0])
-        return self._verify_multiple_mv(pk, n, m, commitment_vec)
+        Transcript.run = None
+        Transcript.cached = (Transcript.fs.verifier_challenges(self, commitment_vec)
+                             if Transcript.fs is not None else None)
+        try:
+            if m == 1:
+                return self._verify_single_mv(pk, n, commitment_vec[0])
+            return self._verify_multiple_mv(pk, n, m, commitment_vec)
+        finally:
+            Transcript.cached = None
 
     def verify(self, pk: PublicKey, n: int, commitment_vec) -> bool:
         # range/mod.rs:57-78 ; True = Ok(()), False = Err(VerificationError)
@@ -729,7 +837,7 @@ class RangeProof:
         F = Fr(G_.r)
         r = G_.r
         T = Transcript
-        y, z = F.new(T.Y_SINGLE), F.new(T.Z_SINGLE)
+        y, z = (F.new(c) for c in T.yz(1))
         one, two = 1, 2
         power_of_two = F.exp_iter_type1(2, n)
         power_of_y = F.exp_iter_type2(y, n)
@@ -750,7 +858,7 @@ class RangeProof:
         r = G_.r
         T = Transcript
         mn = n * m
-        y, z = F.new(T.Y_MULTI), F.new(T.Z_MULTI)
+        y, z = (F.new(c) for c in T.yz(m))
         minus_z = (-z) % r
         z_sqr = z * z % r
         power_of_two = F.exp_iter_type1(2, n)

@@ -43,8 +43,11 @@ def run_verifier_device(torch, bv, records, scalars, want_scalars=True, want_res
     return ok, os_, or_
 
 
-def run_combined_device(torch, bv, records, scalars, seed=12345):
-    """Combined batch check on device -> (ok_flag, partial bytes as numpy uint8)"""
+def run_combined_device(torch, bv, records, scalars, seed=12345, index_base=0, weights=None):
+    """Combined batch check on device -> (ok_flag, partial bytes as numpy uint8).  The 32-byte weight key is derived
+    from `seed` (tests want repeatable weights; production callers pass os.urandom(32)); weights: (count, 2) uint64
+    to supply the 128-bit weights directly."""
+    import hashlib
     dev = torch.device("cuda:0")
     count = records.shape[0]
     d_pts = torch.from_numpy(np.ascontiguousarray(records).view(np.int64)).to(dev)
@@ -53,7 +56,12 @@ def run_combined_device(torch, bv, records, scalars, seed=12345):
     d_part = torch.zeros(bv.partial_bytes(), dtype=torch.uint8, device=dev)
     wsb = bv.combined_workspace_bytes(count)
     d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    bv.run_combined_device(d_pts.data_ptr(), d_sc.data_ptr(), count, seed, d_part.data_ptr(), d_ok.data_ptr(),
-                           d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream)
+    key = hashlib.sha256(b"test weight key %d" % seed).digest()
+    d_w = None
+    if weights is not None:
+        d_w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.uint64).view(np.int64)).to(dev)
+    bv.run_combined_device(d_pts.data_ptr(), d_sc.data_ptr(), count, key, index_base, d_part.data_ptr(), d_ok.data_ptr(),
+                           d_ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream,
+                           d_weights=d_w.data_ptr() if d_w is not None else 0)
     torch.cuda.synchronize()
     return int(d_ok.item()), d_part.cpu().numpy()

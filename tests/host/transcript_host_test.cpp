@@ -1,0 +1,69 @@
+// Host-side harness for csrc/sha256.hpp and csrc/transcript.hpp (compiled with g++, no GPU needed).
+//   sha <hex message> [repeat]      -> SHA-256 digest (hex) of the message repeated `repeat` times
+//   hmac <hex key> <hex message>    -> HMAC-SHA-256 (hex)
+//   tr <file>                       -> file: u32 LE [curve, n, m, k, pk_nwords, rec_nwords] + pk words + record
+//                                      words; prints st0 (8 words) and the challenge block [y, z, e, e_1..e_k]
+//                                      (8 words each) as hex words, one per line
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../bulletproofsplus_amd/csrc/ed25519.hpp"
+#include "../../bulletproofsplus_amd/csrc/transcript.hpp"
+using namespace bpp;
+
+static std::vector<uint8_t> unhex(const char* h) {
+    std::vector<uint8_t> v;
+    size_t n = strlen(h);
+    for (size_t i = 0; i + 1 < n; i += 2) {
+        unsigned x;
+        sscanf(h + i, "%2x", &x);
+        v.push_back((uint8_t)x);
+    }
+    return v;
+}
+static void print_digest(const uint32_t d[8]) {
+    for (int i = 0; i < 8; i++) printf("%08x", d[i]);
+    printf("\n");
+}
+int main(int argc, char** argv) {
+    if (argc >= 3 && !strcmp(argv[1], "sha")) {
+        std::vector<uint8_t> m = unhex(argv[2]);
+        const long rep = argc > 3 ? atol(argv[3]) : 1;
+        Sha256 s;
+        sha256_init(s);
+        for (long r = 0; r < rep; r++) sha256_update(s, m.data(), m.size());
+        uint32_t d[8];
+        sha256_final(s, d);
+        print_digest(d);
+        return 0;
+    }
+    if (argc >= 4 && !strcmp(argv[1], "hmac")) {
+        std::vector<uint8_t> k = unhex(argv[2]), m = unhex(argv[3]);
+        uint32_t d[8];
+        hmac_sha256(k.data(), k.size(), m.data(), m.size(), d);
+        print_digest(d);
+        return 0;
+    }
+    if (argc >= 3 && !strcmp(argv[1], "tr")) {
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 2;
+        uint32_t hdr[6];
+        if (fread(hdr, 4, 6, f) != 6) return 2;
+        std::vector<uint32_t> pk(hdr[4]), rec(hdr[5]);
+        if (fread(pk.data(), 4, pk.size(), f) != pk.size() || fread(rec.data(), 4, rec.size(), f) != rec.size()) return 2;
+        fclose(f);
+        const uint32_t curve = hdr[0], n = hdr[1], m = hdr[2], k = hdr[3];
+        uint32_t st0[8];
+        tr_initial_state((int)curve, n, m, pk.data(), pk.size(), st0);
+        std::vector<uint32_t> out((size_t)(3 + k) * 8);
+        if (curve == 0) tr_verifier_challenges<Bls12381>(st0, rec.data(), k, m, n * m, out.data());
+        else if (curve == 1) tr_verifier_challenges<Secp256k1>(st0, rec.data(), k, m, n * m, out.data());
+        else tr_verifier_challenges<Ed25519>(st0, rec.data(), k, m, n * m, out.data());
+        for (int i = 0; i < 8; i++) printf("%08x\n", st0[i]);
+        for (uint32_t w : out) printf("%08x\n", w);
+        return 0;
+    }
+    return 1;
+}
