@@ -475,8 +475,10 @@ def _verifier_sum_partials_device(self, d_partials: int, n: int, d_ok: int, stre
           "bpp_verifier_sum_partials")
 
 
-def _engine_prove_batch(self, values, gammas):
+def _engine_prove_batch(self, values, gammas, transcript: bool = False):
     """RangeProof::prove + RangeProver::commit for `count` provers sharing this engine's (pk, n, m).
+    transcript=True: challenges from the Fiat-Shamir transcript (csrc/transcript.hpp) instead of the reference's
+    constants -- not a reference code path, parity unpinned.
     values: (count, m) ints < 2^64 ; gammas: (count, m) scalars (ints or (count, m, 4) uint64).
     Returns (points (count, 3+2k, PW), scalars (count, 3, 4), V (count, m, PW)) in wire format --
     bit-identical to RangeProof.prove / RangeProver.commit one by one."""
@@ -493,8 +495,8 @@ def _engine_prove_batch(self, values, gammas):
     pts = np.zeros((count, 3 + 2 * self.k, PW), dtype=np.uint64)
     sc = np.zeros((count, 3, 4), dtype=np.uint64)
     V = np.zeros((count, self.m, PW), dtype=np.uint64)
-    check(_lib.lib().bpp_range_prove_batch(self.handle, _ptr(vals), _ptr(gm), count, _ptr(pts), _ptr(sc), _ptr(V)),
-          "bpp_range_prove_batch")
+    fn = _lib.lib().bpp_range_prove_batch_fs if transcript else _lib.lib().bpp_range_prove_batch
+    check(fn(self.handle, _ptr(vals), _ptr(gm), count, _ptr(pts), _ptr(sc), _ptr(V)), "bpp_range_prove_batch")
     return pts, sc, V
 
 
@@ -503,8 +505,15 @@ def _engine_prover_workspace_bytes(self, count: int) -> int:
 
 
 def _engine_prove_batch_device(self, d_values: int, d_gammas: int, count: int, d_out_points: int, d_out_scalars: int,
-                               d_out_V: int, d_workspace: int, workspace_bytes: int, stream: int = 0):
+                               d_out_V: int, d_workspace: int, workspace_bytes: int, stream: int = 0,
+                               transcript: bool = False, d_out_challenges: int = 0):
     """prove_batch with every buffer in HBM (raw device pointers), asynchronous on `stream`."""
+    if transcript:
+        check(_lib.lib().bpp_range_prove_batch_fs_device(self.handle, d_values, d_gammas, count, d_out_points,
+                                                         d_out_scalars, d_out_V or None, d_out_challenges or None,
+                                                         d_workspace, workspace_bytes, stream or None),
+              "bpp_range_prove_batch_fs_device")
+        return
     check(_lib.lib().bpp_range_prove_batch_device(self.handle, d_values, d_gammas, count, d_out_points, d_out_scalars,
                                                   d_out_V or None, d_workspace, workspace_bytes, stream or None),
           "bpp_range_prove_batch_device")

@@ -147,7 +147,17 @@ extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, co
     if (count == 0) return BPP_OK;
     HIPCHK(hipSetDevice(engine->ctx.device));
     return dispatch(engine->ctx.curve, [&](auto cv) -> int {
-        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V);
+        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V, false);
+    });
+}
+
+extern "C" int bpp_range_prove_batch_fs(bpp_verifier* engine, const uint64_t* v, const uint64_t* gamma, size_t count,
+                                        uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+    if (!engine || !v || !gamma || !out_points || !out_scalars) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(engine->ctx.device));
+    return dispatch(engine->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V, true);
     });
 }
 
@@ -161,18 +171,33 @@ extern "C" size_t bpp_prover_workspace_bytes(const bpp_verifier* engine, size_t 
     return r;
 }
 
-extern "C" int bpp_range_prove_batch_device(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma,
-                                            size_t count, uint64_t* d_out_points, uint64_t* d_out_scalars,
-                                            uint64_t* d_out_V, void* d_workspace, size_t workspace_bytes, void* stream) {
+static int prove_batch_device_common(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma, size_t count,
+                                     uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
+                                     uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!engine || !d_v || !d_gamma || !d_out_points || !d_out_scalars || !d_workspace)
         return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
     HIPCHK(hipSetDevice(engine->ctx.device));
     return dispatch(engine->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::prove_batch_device(engine, d_v, d_gamma, count, d_out_points, d_out_scalars,
-                                                            d_out_V, d_workspace, workspace_bytes,
+                                                            d_out_V, fs, d_out_challenges, d_workspace, workspace_bytes,
                                                             static_cast<hipStream_t>(stream));
     });
+}
+
+extern "C" int bpp_range_prove_batch_device(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma,
+                                            size_t count, uint64_t* d_out_points, uint64_t* d_out_scalars,
+                                            uint64_t* d_out_V, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return prove_batch_device_common(engine, d_v, d_gamma, count, d_out_points, d_out_scalars, d_out_V, false, nullptr,
+                                     d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int bpp_range_prove_batch_fs_device(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma,
+                                               size_t count, uint64_t* d_out_points, uint64_t* d_out_scalars,
+                                               uint64_t* d_out_V, uint64_t* d_out_challenges, void* d_workspace,
+                                               size_t workspace_bytes, void* stream) {
+    return prove_batch_device_common(engine, d_v, d_gamma, count, d_out_points, d_out_scalars, d_out_V, true,
+                                     d_out_challenges, d_workspace, workspace_bytes, stream);
 }
 
 // ---- combined batch check ------------------------------------------------------------------------------

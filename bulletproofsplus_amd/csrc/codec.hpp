@@ -172,7 +172,7 @@ struct CodecImpl {
     static constexpr int N = C::Fp::N;
     static constexpr int WW = 2 * N + 2;
 
-    static int compress(const uint64_t* points, size_t n, uint8_t* out) {
+    BPP_NOINL static int compress(const uint64_t* points, size_t n, uint8_t* out) {
         if constexpr (!has_codec<C>::value) {
             return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
         } else {
@@ -191,7 +191,7 @@ struct CodecImpl {
     }
 
     // device to device: `d_in` n x CB bytes, `d_wire` n wire points, `d_ok` n words
-    static int decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st) {
+    BPP_NOINL static int decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st) {
         if constexpr (!has_codec<C>::value) {
             return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
         } else {
@@ -203,7 +203,7 @@ struct CodecImpl {
         }
     }
 
-    static int decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
+    BPP_NOINL static int decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
         if constexpr (!has_codec<C>::value) {
             return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
         } else {

@@ -18,6 +18,11 @@ struct bpp_ctx {
     int device;
 };
 
+// Entry points of the per-curve implementation structs (impl_*.hpp, codec.hpp).  They are defined in class, hence
+// implicitly inline, and `extern template` does not stop the compiler from instantiating an inline function in order
+// to inline it: without this attribute capi.hip compiled every kernel of every curve a second time (8 minutes, 12 MB).
+#define BPP_NOINL __attribute__((noinline))
+
 // ---- error handling ------------------------------------------------------------------------------------
 inline thread_local std::string g_err;
 inline int fail(int code, const std::string& msg) {

@@ -70,7 +70,7 @@ struct MsmImpl {
     static constexpr int PW = WW / 2;     // 64-bit words per wire point
 
     // `count` MulVecs over device-resident affm points / canonical scalars -> wire points on the host
-    static int msm_batch_dev(const uint32_t* d_scalars, const uint32_t* d_points, const std::vector<uint64_t>& offsets,
+    BPP_NOINL static int msm_batch_dev(const uint32_t* d_scalars, const uint32_t* d_points, const std::vector<uint64_t>& offsets,
                              uint64_t* out, hipStream_t st) {
         const size_t count = offsets.size() - 1;
         if (count == 0) return BPP_OK;
@@ -98,7 +98,7 @@ struct MsmImpl {
 
     // one large MulVec through the bucket method (pippenger.hpp); window_bits = 0 picks it from n
     static constexpr size_t PIPPENGER_MIN_N = 4096;
-    static int msm_pippenger_dev(const uint32_t* d_scalars, const uint32_t* d_points, size_t n, int window_bits,
+    BPP_NOINL static int msm_pippenger_dev(const uint32_t* d_scalars, const uint32_t* d_points, size_t n, int window_bits,
                                  uint64_t* out, hipStream_t st) {
         if (n >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "n too large");
         const PipShape ps = pip_shape(n, window_bits ? window_bits : pip_pick_c(n));
@@ -116,7 +116,7 @@ struct MsmImpl {
     }
 
     // explicit window width (tests sweep it); host pointers
-    static int msm_pippenger(const uint64_t* scalars, const uint64_t* points, size_t n, int window_bits, uint64_t* out) {
+    BPP_NOINL static int msm_pippenger(const uint64_t* scalars, const uint64_t* points, size_t n, int window_bits, uint64_t* out) {
         if (window_bits && (window_bits < 2 || window_bits > 16)) return fail(BPP_E_ARG, "window_bits must be in [2, 16]");
         if (n == 0) {
             std::memset(out, 0, WW * 4);
@@ -131,7 +131,7 @@ struct MsmImpl {
         return msm_pippenger_dev(dsc.u32(), dpt.u32(), n, window_bits, out, nullptr);
     }
 
-    static int msm_batch(const uint64_t* scalars, const uint64_t* points, const uint32_t* lens, size_t count,
+    BPP_NOINL static int msm_batch(const uint64_t* scalars, const uint64_t* points, const uint32_t* lens, size_t count,
                          uint64_t* out) {
         std::vector<uint64_t> off(count + 1, 0);
         for (size_t c = 0; c < count; c++) off[c + 1] = off[c] + lens[c];
@@ -145,7 +145,7 @@ struct MsmImpl {
         return msm_batch_dev(dsc.u32(), dpt.u32(), off, out, nullptr);
     }
 
-    static int scalar_mul_batch(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t* out) {
+    BPP_NOINL static int scalar_mul_batch(const uint64_t* scalars, const uint64_t* points, size_t n, uint64_t* out) {
         if (n == 0) return BPP_OK;
         DevBuf dsc, dpt, dres, dw;
         int rc = upload_scalars<C>(scalars, n, dsc, nullptr);
@@ -164,7 +164,7 @@ struct MsmImpl {
     }
 
     // PublicKey::new (publickey.rs:21-48)
-    static int pk_new(size_t length, uint64_t* out_gh, uint64_t* out_G, uint64_t* out_H) {
+    BPP_NOINL static int pk_new(size_t length, uint64_t* out_gh, uint64_t* out_G, uint64_t* out_H) {
         const size_t total = 2 + 2 * length;
         // scalars: [1, 2, 3(i+1).., 5(i+1)..] with Rust's `i as i32` wrap (publickey.rs:29-39)
         std::vector<uint32_t> sc(total * 8);
@@ -203,7 +203,7 @@ struct MsmImpl {
     }
 
     // RangeProver::commit (prover.rs:28-42)
-    static int commit(const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out) {
+    BPP_NOINL static int commit(const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out) {
         uint32_t sc[16];
         scalar_from_i32<C>((int32_t)(uint32_t)v, sc);  // `v as i32`, prover.rs:37
         std::memcpy(sc + 8, gamma, 32);
@@ -213,7 +213,7 @@ struct MsmImpl {
 
     // RangeProof::verify for one proof, without window tables: verifier scalars on the device, then the
     // MulVec exactly as the reference assembles it (range/mod.rs:480-509 / wip.rs:297-327).
-    static int range_verify_single(const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
+    BPP_NOINL static int range_verify_single(const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
                                    const uint64_t* proof_points, size_t k, const uint64_t* proof_scalars,
                                    const uint64_t* V) {
         VerifyShape s;
@@ -266,7 +266,7 @@ struct MsmImpl {
     }
 
     // field: 0 = base field, 1 = scalar field
-    static int debug_field_op(int field, int op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
+    BPP_NOINL static int debug_field_op(int field, int op, const uint32_t* a, const uint32_t* b, size_t n, uint32_t* out) {
         auto run = [&](auto pv) -> int {
             using P = decltype(pv);
             DevBuf da, db, dout;
@@ -286,7 +286,7 @@ struct MsmImpl {
         return run(typename C::Fr{});
     }
 
-    static int debug_point_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+    BPP_NOINL static int debug_point_op(int op, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
         DevBuf da, db, dout;
         const size_t bytes = n * WW * 4;
         HIPCHK(da.alloc(bytes));

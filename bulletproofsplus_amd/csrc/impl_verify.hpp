@@ -100,7 +100,7 @@ struct VerifyImpl {
         return w;
     }
 
-    static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
+    BPP_NOINL static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
                       int window_bits, bpp_verifier** out) {
         VerifyShape s;
         int rc = make_shape(n, m, window_bits, C::Fr::MODW, C::Fr::BITS, s);
@@ -158,7 +158,7 @@ struct VerifyImpl {
         return BPP_OK;
     }
 
-    static int run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+    BPP_NOINL static int run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
                    const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
                    uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st) {
         const VerifyShape& s = v->s;
@@ -210,7 +210,7 @@ struct VerifyImpl {
         const unsigned hb = tree ? cdiv(count, FIXED_BLOCK / 64) : cdiv(count, FIXED_BLOCK);
         uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
         hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree);
+                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u});
         HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
         // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
@@ -238,7 +238,7 @@ struct VerifyImpl {
         return BPP_OK;
     }
 
-    static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
+    BPP_NOINL static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
                                  hipStream_t st) {
         hipLaunchKernelGGL(k_transcript_challenges<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, v->s, v->tr0,
                            reinterpret_cast<const uint32_t*>(d_points), reinterpret_cast<uint32_t*>(d_challenges), count);
@@ -287,7 +287,7 @@ struct VerifyImpl {
     }
 
     // d_out_partial: one jacobian (3N words, opaque to the caller) = this batch's weighted sum
-    static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+    BPP_NOINL static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
                             const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
                             const uint64_t* d_weights, uint32_t* d_out_partial, uint32_t* d_ok, void* d_workspace,
                             size_t workspace_bytes, hipStream_t st) {
@@ -344,7 +344,8 @@ struct VerifyImpl {
         // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
         // leading block; the Horner result lands behind the block sums
         hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
-                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u);
+                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u,
+                           VpSel{1u, 0u, 1u});
         hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
                            d_out_partial);
         hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
@@ -356,7 +357,7 @@ struct VerifyImpl {
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
     // and nothing synchronises.  The batch is processed in chunks that reuse one workspace.
     struct ProveLayout {
-        size_t a, b, cG, cH, pwy, con, vps, part, vout, total;
+        size_t a, b, cG, cH, pwy, con, vps, part, vout, trst, ch, total;
         size_t chunk;
         unsigned per;
     };
@@ -392,14 +393,22 @@ struct VerifyImpl {
         o += al(nv_total * w.per * JW * 4);
         w.vout = o;
         o += al(w.chunk * (size_t)s.m * WW * 4);   // the commitments of a chunk when the caller does not want them
+        w.trst = o;
+        o += al(w.chunk * 32);                      // transcript states (Fiat-Shamir mode)
+        w.ch = o;
+        o += al(w.chunk * (size_t)(3 + s.k) * 32);  // ... and the challenge blocks when the caller does not want them
         w.total = o;
         return w;
     }
     // d_values: count x m u64 ; d_gammas: count x m scalars ; d_out_points: count x (3 + 2k) wire points ;
-    // d_out_scalars: count x 3 scalars ; d_out_V: count x m wire points (may be null)
-    static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
-                                  uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, void* d_workspace,
-                                  size_t workspace_bytes, hipStream_t st) {
+    // d_out_scalars: count x 3 scalars ; d_out_V: count x m wire points (may be null).
+    // fs = false: the reference's constant challenges, every MulVec of the batch in ONE k_fixed_msm launch.
+    // fs = true : challenges from the transcript (transcript.hpp): A and the commitments first, then y, z; each round's
+    //             L_t, R_t before e_t; wip.A, wip.B before e -- 3 + k smaller launches and the hashing steps between
+    //             them.  d_out_challenges (count x (3 + k) scalars, may be null) receives [y, z, e, e_1..e_k].
+    BPP_NOINL static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
+                                  uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
+                                  uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st) {
         const VerifyShape& s = v->s;
         const uint32_t k = s.k, m = s.m;
         const uint32_t nvp = pb_num_vps(k, m);
@@ -417,33 +426,65 @@ struct VerifyImpl {
         auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
         for (size_t base = 0; base < count; base += L.chunk) {
             const size_t cnt = std::min(L.chunk, count - base);
-            const size_t nv_total = cnt * nvp;
-            // the launch geometry is the one the workspace was sized for (a smaller last chunk may use fewer blocks)
-            const unsigned per = std::min(L.per, blocks_per_proof(s, nv_total));
             uint32_t* o_pts = reinterpret_cast<uint32_t*>(d_out_points) + base * (size_t)(3 + 2 * k) * WW;
             uint32_t* o_sc = reinterpret_cast<uint32_t*>(d_out_scalars) + base * 24;
             uint32_t* o_V = d_out_V ? reinterpret_cast<uint32_t*>(d_out_V) + base * (size_t)m * WW : W(L.vout);
-            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, d_values + base * m,
-                               reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8, v->challenges.u32(), 0u,
-                               W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            for (uint32_t t = 0; t < k; t++)
-                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, W(L.a), W(L.b), W(L.cG),
-                                   W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, W(L.a), W(L.b), W(L.cG),
-                               W(L.cH), W(L.con), W(L.vps), o_sc);
-            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv_total * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st,
-                               s, W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
-                               (uint32_t*)nullptr, (size_t)0, 0u);
-            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv_total, 64)), dim3(64), 0, st, s, W(L.part), per, o_pts, o_V,
-                               nv_total);
+            const uint64_t* vals = d_values + base * m;
+            const uint32_t* gams = reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8;
+            // one MulVec launch over `sel` of every proof's virtual proofs, then their wire points into the records
+            auto msm = [&](VpSel sel) {
+                const size_t nv = cnt * sel.cnt;
+                // never more blocks per virtual proof than the workspace was sized for
+                const unsigned per = std::min(L.per, blocks_per_proof(s, nv));
+                hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
+                                   W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
+                                   (uint32_t*)nullptr, (size_t)0, 0u, sel);
+                hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv, 64)), dim3(64), 0, st, s, sel, W(L.part), per, o_pts, o_V, nv);
+            };
+            if (!fs) {
+                hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, 0u, vals, gams,
+                                   v->challenges.u32(), 0u, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+                for (uint32_t t = 0; t < k; t++)
+                    hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_ALL, W(L.a),
+                                       W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+                hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, W(L.a), W(L.b),
+                                   W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
+                msm(VpSel{nvp, 0u, nvp});
+                continue;
+            }
+            uint32_t* o_ch = d_out_challenges ? reinterpret_cast<uint32_t*>(d_out_challenges) + base * (size_t)(3 + k) * 8
+                                              : W(L.ch);
+            const uint32_t chs = (3 + k) * 8;
+            const unsigned lanes = cdiv(cnt, 64);
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
+                               chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            msm(VpSel{nvp, 0u, 1u});               // A
+            msm(VpSel{nvp, 2 * k + 3, m});         // V_0 .. V_{m-1}
+            hipLaunchKernelGGL(k_pb_fs_yz<C>, dim3(lanes), dim3(64), 0, st, s, v->tr0, o_pts, o_V, W(L.trst), o_ch, cnt);
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
+                               chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            for (uint32_t t = 0; t < k; t++) {
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
+                                   W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+                msm(VpSel{nvp, 1 + 2 * t, 2u});    // L_t, R_t
+                hipLaunchKernelGGL(k_pb_fs_round<C>, dim3(lanes), dim3(64), 0, st, s, t, o_pts, W(L.trst), o_ch, W(L.con), cnt);
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_POST, W(L.a),
+                                   W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            }
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, W(L.a), W(L.b),
+                               W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
+            msm(VpSel{nvp, 2 * k + 1, 2u});        // wip.A, wip.B
+            hipLaunchKernelGGL(k_pb_fs_final<C>, dim3(lanes), dim3(64), 0, st, s, o_pts, W(L.trst), o_ch, W(L.con), cnt);
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, W(L.a), W(L.b),
+                               W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
         }
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }
 
     // host buffers in, host buffers out
-    static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
-                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+    BPP_NOINL static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
+                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs) {
         const VerifyShape& s = v->s;
         const uint32_t k = s.k, m = s.m;
         hipStream_t st = nullptr;
@@ -459,7 +500,7 @@ struct VerifyImpl {
         HIPCHK(d_ws.alloc(L.total));
         rc = prove_batch_device(v, static_cast<const uint64_t*>(d_val.p), static_cast<const uint64_t*>(d_gam.p), count,
                                 static_cast<uint64_t*>(d_pts.p), static_cast<uint64_t*>(d_sc.p),
-                                static_cast<uint64_t*>(d_V.p), d_ws.p, L.total, st);
+                                static_cast<uint64_t*>(d_V.p), fs, nullptr, d_ws.p, L.total, st);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out_points, d_pts.p, count * (size_t)(3 + 2 * k) * WW * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(out_scalars, d_sc.p, count * 96, hipMemcpyDeviceToHost, st));
@@ -469,7 +510,7 @@ struct VerifyImpl {
     }
 
     // d_partials: n partials as bpp_verifier_run_combined wrote them (jacobian + validity word each)
-    static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
+    BPP_NOINL static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
         hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n,
                            (uint32_t)partial_words<C>(), 1u, d_ok, (uint32_t*)nullptr);
         HIPCHK(hipGetLastError());

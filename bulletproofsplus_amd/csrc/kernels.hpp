@@ -758,6 +758,14 @@ constexpr unsigned fixed_lds_bytes() {
     return (FIXED_BLOCK / 64) * (FIXED_RING * (2 * C::Fp::N / 4) + 2) * 1024;
 }
 
+// Which scalar arrays a k_fixed_msm launch runs over.  The verifier's arrays are one per proof (nvp = 1, first = 0,
+// cnt = 1).  The batched prover keeps nvp "virtual proofs" per real proof (its L_t, R_t, A, B, commitments: each a
+// MulVec over the same fixed generators) and launches either all of them or, under the Fiat-Shamir transcript, the
+// cnt consecutive ones a step has just produced: flat index b of the launch -> array (b / cnt) * nvp + first + b % cnt.
+struct VpSel {
+    uint32_t nvp, first, cnt;
+};
+
 // Fixed-generator part: for proof b, sum_f scalar_f * F_f through the window tables.
 // scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
 // one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
@@ -779,7 +787,7 @@ template <class C, int ROLE = 0>
 __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per,
                             uint32_t horner_blocks, const uint32_t* __restrict__ wsum, uint32_t* __restrict__ var_out,
-                            size_t horner_count, uint32_t horner_tree) {
+                            size_t horner_count, uint32_t horner_tree, VpSel sel) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     constexpr int CH = 2 * N / 4;                              // 16-byte pieces of a table entry
@@ -799,7 +807,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(Veri
     const uint32_t bid = blockIdx.x - horner_blocks;
     const size_t b = bid / per;
     const uint32_t part = bid % per;
-    const uint32_t* sc = scalars + b * (size_t)s.N * 8;
+    const uint32_t* sc = scalars + ((b / sel.cnt) * sel.nvp + sel.first + b % sel.cnt) * (size_t)s.N * 8;
     const uint32_t mask = (1u << s.c) - 1u;
     const uint32_t stride = per * blockDim.x;
     const uint32_t lane = threadIdx.x & 63u;

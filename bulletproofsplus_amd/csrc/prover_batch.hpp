@@ -57,10 +57,21 @@ __device__ __forceinline__ void pb_st_canon(uint32_t* p, const Fe<P>& x) {
     st_words<8>(p, w);
 }
 
+// phases of the per-proof kernels.  In the reference's constants mode every challenge is known up front and each
+// kernel runs whole (PB_ALL).  Under the Fiat-Shamir transcript (transcript.hpp) a challenge exists only after the
+// points it binds have been computed, so the same kernels run in two halves around the MulVecs and the hashing:
+//   k_pb_init : PB_PRE  = what needs no challenge (the scalars of A and of the commitments V_j)
+//               PB_POST = what needs y, z (vectors a, b, y-powers, alpha_hat)
+//   k_pb_round: PB_PRE  = the scalars of L_t, R_t ;  PB_POST = the fold with e_t
+//   k_pb_final: PB_PRE  = the scalars of wip.A, wip.B ;  PB_POST = r', s', delta' with e
+enum { PB_ALL = 0, PB_PRE = 1, PB_POST = 2 };
+
 // One block (256 threads) per proof.  values: [count][m] u64 ; gammas: [count][m][8] canonical ;
-// challenges: [y, z, e, e_1..e_k] (shared when ch_stride == 0).
+// challenges: [y, z, e, e_1..e_k] (shared when ch_stride == 0).  fs: the round challenges are not known yet (only
+// y and z are read; e_t and e_t^-1 are filled in round by round by k_pb_fs_round).
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc, const uint64_t* __restrict__ values,
+__global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc, uint32_t phase, uint32_t fs,
+                                                 const uint64_t* __restrict__ values,
                                                  const uint32_t* __restrict__ gammas,
                                                  const uint32_t* __restrict__ challenges, uint32_t ch_stride,
                                                  uint32_t* __restrict__ st_a, uint32_t* __restrict__ st_b,
@@ -81,6 +92,36 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
     const uint32_t nvp = pb_num_vps(k, m);
     uint32_t* vp0 = vps + p * (size_t)nvp * s.N * 8;
 
+    if (phase != PB_POST) {
+        // zero the virtual-proof arrays of this proof
+        uint4* q = reinterpret_cast<uint4*>(vp0);
+        const size_t n16 = (size_t)nvp * s.N * 2;
+        for (size_t t = tid; t < n16; t += blockDim.x) q[t] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        // virtual proof 0: range A = alpha h + sum (bit ? G_i : -H_i)          (range/mod.rs:94-107 / :256-277)
+        const F one_ = F::one(), minus_one_ = fe_neg(one_);
+        for (uint32_t i = tid; i < mn; i += blockDim.x) {
+            const uint32_t i1 = i % n, i2 = i / n;
+            const uint32_t bit = (uint32_t)((values[p * m + i2] >> i1) & 1ull);
+            if (bit) pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + i) * 8, one_);
+            else pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + mn + i) * 8, minus_one_);
+        }
+        if (tid == 0) {
+            pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.alpha));
+            for (uint32_t j = 0; j < m; j++) {
+                // commitment V_j = new(v as i32) g + gamma h            (range/prover.rs:34-40)
+                uint32_t w[8];
+                ld_words<8>(gammas + (p * m + j) * 8, w);
+                const F g = fe_from_canonical<P>(w);
+                uint32_t* vpV = vp0 + (size_t)(2 * k + 3 + j) * s.N * 8;
+                const int32_t vi = (int32_t)(uint32_t)values[p * m + j];
+                pb_st_canon<P>(vpV + (size_t)fixed_term_index(s, 0) * 8, fe_from_i32<P>(vi));
+                pb_st_canon<P>(vpV + (size_t)fixed_term_index(s, 1) * 8, g);
+            }
+        }
+        if (phase == PB_PRE) return;
+        __syncthreads();
+    }
     if (tid == 0) {
         // batched inversion of [y, e_1..e_k] (one fe_inv), power table y^(2^b)
         uint32_t w[8];
@@ -88,27 +129,31 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         const F y = fe_from_canonical<P>(w);
         ld_words<8>(ch + 8, w);
         const F z = fe_from_canonical<P>(w);
-        ld_words<8>(ch + 16, w);
-        const F ef = fe_from_canonical<P>(w);
         pb_st<P>(consts + 2 * 8, y);
         pb_st<P>(consts + 3 * 8, z);
-        pb_st<P>(consts + 4 * 8, ef);
-        F acc = y;  // prefix products kept in the e^-1 slots
-        for (uint32_t t = 0; t < k; t++) {
-            ld_words<8>(ch + (3 + t) * 8, w);
-            const F e = fe_from_canonical<P>(w);
-            pb_st<P>(consts + (5 + t) * 8, e);
-            pb_st<P>(consts + (5 + k + t) * 8, acc);   // prefix before e_t
-            acc = fe_mul(acc, e);
+        if (fs) {
+            pb_st<P>(consts + 0, fe_inv(y));  // y^-1 ; e, e_t, e_t^-1 arrive later (k_pb_fs_round / k_pb_fs_final)
+        } else {
+            ld_words<8>(ch + 16, w);
+            const F ef = fe_from_canonical<P>(w);
+            pb_st<P>(consts + 4 * 8, ef);
+            F acc = y;  // prefix products kept in the e^-1 slots
+            for (uint32_t t = 0; t < k; t++) {
+                ld_words<8>(ch + (3 + t) * 8, w);
+                const F e = fe_from_canonical<P>(w);
+                pb_st<P>(consts + (5 + t) * 8, e);
+                pb_st<P>(consts + (5 + k + t) * 8, acc);   // prefix before e_t
+                acc = fe_mul(acc, e);
+            }
+            F inv = fe_inv(acc);
+            for (uint32_t t = k; t-- > 0;) {
+                const F e = pb_ld<P>(consts + (5 + t) * 8);
+                const F pre = pb_ld<P>(consts + (5 + k + t) * 8);
+                pb_st<P>(consts + (5 + k + t) * 8, fe_mul(inv, pre));  // e_t^-1
+                inv = fe_mul(inv, e);
+            }
+            pb_st<P>(consts + 0, inv);  // y^-1
         }
-        F inv = fe_inv(acc);
-        for (uint32_t t = k; t-- > 0;) {
-            const F e = pb_ld<P>(consts + (5 + t) * 8);
-            const F pre = pb_ld<P>(consts + (5 + k + t) * 8);
-            pb_st<P>(consts + (5 + k + t) * 8, fe_mul(inv, pre));  // e_t^-1
-            inv = fe_mul(inv, e);
-        }
-        pb_st<P>(consts + 0, inv);  // y^-1
         F yy = y;
         for (uint32_t bnum = 0; bnum <= k + 1; bnum++) {
             sh_ypw[bnum] = yy;
@@ -128,17 +173,11 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         w[t >> 5] = 1u << (t & 31);
         sh_p2[t] = fe_from_canonical<P>(w);
     }
-    // zero the virtual-proof arrays of this proof
-    {
-        uint4* q = reinterpret_cast<uint4*>(vp0);
-        const size_t n16 = (size_t)nvp * s.N * 2;
-        for (size_t t = tid; t < n16; t += blockDim.x) q[t] = make_uint4(0, 0, 0, 0);
-    }
     __syncthreads();
 
     const F one = F::one();
     const F z = sh_z;
-    const F nz = fe_neg(z), one_minus_z = fe_sub(one, z), minus_one = fe_neg(one);
+    const F nz = fe_neg(z), one_minus_z = fe_sub(one, z);
     // pwy[i] = y^(i+1)
     for (uint32_t i = tid; i < mn; i += blockDim.x) {
         F yp = one;
@@ -148,7 +187,6 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         pb_st<P>(st_pwy + (p * mn + i) * 8, yp);
     }
     __syncthreads();
-    uint32_t* vpA = vp0;  // virtual proof 0: range A = alpha h + sum (bit ? G_i : -H_i)
     for (uint32_t i = tid; i < mn; i += blockDim.x) {
         const uint32_t i1 = i % n, i2 = i / n;
         const uint32_t bit = (uint32_t)((values[p * m + i2] >> i1) & 1ull);
@@ -161,12 +199,9 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         pb_st<P>(st_b + (p * mn + i) * 8, bit ? hexp : fe_sub(hexp, one));         // :164-170 / :357-364
         pb_st<P>(st_cG + (p * mn + i) * 8, one);
         pb_st<P>(st_cH + (p * mn + i) * 8, one);
-        if (bit) pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + i) * 8, one);
-        else pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + mn + i) * 8, minus_one);
     }
     if (tid == 0) {
         const F alpha = fe_from_u32<P>(pc.alpha);
-        pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 1) * 8, alpha);
         // alpha_hat = alpha + y^(mn+1) * sum_j pz_j gamma_j        (:172 / :366-376)
         F acc = F::zero();
         for (uint32_t j = 0; j < m; j++) {
@@ -174,11 +209,6 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
             ld_words<8>(gammas + (p * m + j) * 8, w);
             const F g = fe_from_canonical<P>(w);
             acc = fe_add(acc, fe_mul(sh_pz[j], g));
-            // commitment V_j = new(v as i32) g + gamma h            (range/prover.rs:34-40)
-            uint32_t* vpV = vp0 + (size_t)(2 * k + 3 + j) * s.N * 8;
-            const int32_t vi = (int32_t)(uint32_t)values[p * m + j];
-            pb_st_canon<P>(vpV + (size_t)fixed_term_index(s, 0) * 8, fe_from_i32<P>(vi));
-            pb_st_canon<P>(vpV + (size_t)fixed_term_index(s, 1) * 8, g);
         }
         pb_st<P>(consts + 1 * 8, fe_add(alpha, fe_mul(acc, sh_ymn1)));
     }
@@ -187,7 +217,7 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
 // One folding round t (wip.rs:79-172) for every proof: emits the scalar arrays of L_t and R_t, then folds
 // a, b, cG, cH and alpha.  One block (256 threads) per proof.
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc, uint32_t t,
+__global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc, uint32_t t, uint32_t phase,
                                                   uint32_t* __restrict__ st_a, uint32_t* __restrict__ st_b,
                                                   uint32_t* __restrict__ st_cG, uint32_t* __restrict__ st_cH,
                                                   const uint32_t* __restrict__ st_pwy,
@@ -209,6 +239,11 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
     uint32_t* vpL = vps + (p * nvp + 1 + 2 * t) * (size_t)s.N * 8;
     uint32_t* vpR = vpL + (size_t)s.N * 8;
 
+    const F yh = pb_ld<P>(pwy + (size_t)(nh - 1) * 8);   // y^n'            (wip.rs:98)
+    // y^-n' = (y^-1)^(n'), n' a power of two
+    F yhinv = pb_ld<P>(consts + 0);
+    for (uint32_t q = 1; q < nh; q <<= 1) yhinv = fe_sqr(yhinv);
+    if (phase != PB_POST) {
     // c_L = sum a1 b2 y1 ; c_R = sum a2 b1 y2          (wip.rs:90-91, util.rs:117-127)
     F cl = F::zero(), cr = F::zero();
     for (uint32_t i = tid; i < nh; i += blockDim.x) {
@@ -227,21 +262,11 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
         }
         __syncthreads();
     }
-    const F yh = pb_ld<P>(pwy + (size_t)(nh - 1) * 8);   // y^n'            (wip.rs:98)
-    // y^-n' = (y^-1)^(n'), n' a power of two
-    F yhinv = pb_ld<P>(consts + 0);
-    for (uint32_t q = 1; q < nh; q <<= 1) yhinv = fe_sqr(yhinv);
-    const F e = pb_ld<P>(consts + (size_t)(5 + t) * 8);
-    const F einv = pb_ld<P>(consts + (size_t)(5 + k + t) * 8);
     if (tid == 0) {
         pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 0) * 8, redL[0]);
         pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.d_L));
         pb_st_canon<P>(vpR + (size_t)fixed_term_index(s, 0) * 8, redR[0]);
         pb_st_canon<P>(vpR + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.d_R));
-        // alpha += e^2 d_L + e^-2 d_R                                (wip.rs:171)
-        F al = pb_ld<P>(consts + 1 * 8);
-        al = fe_add(al, fe_add(fe_mul(fe_sqr(e), fe_from_u32<P>(pc.d_L)), fe_mul(fe_sqr(einv), fe_from_u32<P>(pc.d_R))));
-        pb_st<P>(consts + 1 * 8, al);
     }
     // scalars of L_t and R_t over the ORIGINAL generators        (wip.rs:100-125)
     for (uint32_t j = tid; j < mn; j += blockDim.x) {
@@ -259,7 +284,17 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
             pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 2 + mn + j) * 8, fe_mul(b2, chh));
         }
     }
+    if (phase == PB_PRE) return;
     __syncthreads();
+    }   // phase != PB_POST
+    const F e = pb_ld<P>(consts + (size_t)(5 + t) * 8);
+    const F einv = pb_ld<P>(consts + (size_t)(5 + k + t) * 8);
+    if (tid == 0) {
+        // alpha += e^2 d_L + e^-2 d_R                                (wip.rs:171)
+        F al = pb_ld<P>(consts + 1 * 8);
+        al = fe_add(al, fe_add(fe_mul(fe_sqr(e), fe_from_u32<P>(pc.d_L)), fe_mul(fe_sqr(einv), fe_from_u32<P>(pc.d_R))));
+        pb_st<P>(consts + 1 * 8, al);
+    }
     // fold the coefficient products (wip.rs:151-163 expressed on scalars)
     const F fG_hi = fe_mul(yhinv, e);
     for (uint32_t j = tid; j < mn; j += blockDim.x) {
@@ -279,7 +314,8 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
 
 // After the k rounds: scalars of wip.A and wip.B, and r', s', delta'   (wip.rs:175-216)
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc, const uint32_t* __restrict__ st_a,
+__global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc, uint32_t phase,
+                                                  const uint32_t* __restrict__ st_a,
                                                   const uint32_t* __restrict__ st_b,
                                                   const uint32_t* __restrict__ st_cG,
                                                   const uint32_t* __restrict__ st_cH,
@@ -295,20 +331,25 @@ __global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc
     uint32_t* vpA = vps + (p * nvp + 2 * k + 1) * (size_t)s.N * 8;
     uint32_t* vpB = vpA + (size_t)s.N * 8;
     const F r = fe_from_u32<P>(pc.r), sc = fe_from_u32<P>(pc.s);
-    for (uint32_t j = tid; j < mn; j += blockDim.x) {
-        pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + j) * 8, fe_mul(r, pb_ld<P>(st_cG + (p * mn + j) * 8)));
-        pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + mn + j) * 8, fe_mul(sc, pb_ld<P>(st_cH + (p * mn + j) * 8)));
-    }
+    if (phase != PB_POST)
+        for (uint32_t j = tid; j < mn; j += blockDim.x) {
+            pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + j) * 8, fe_mul(r, pb_ld<P>(st_cG + (p * mn + j) * 8)));
+            pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + mn + j) * 8, fe_mul(sc, pb_ld<P>(st_cH + (p * mn + j) * 8)));
+        }
     if (tid == 0) {
-        const F y = pb_ld<P>(consts + 2 * 8), ef = pb_ld<P>(consts + 4 * 8), alpha = pb_ld<P>(consts + 1 * 8);
+        const F y = pb_ld<P>(consts + 2 * 8), alpha = pb_ld<P>(consts + 1 * 8);
         const F a0 = pb_ld<P>(st_a + p * (size_t)mn * 8), b0 = pb_ld<P>(st_b + p * (size_t)mn * 8);
         const F delta = fe_from_u32<P>(pc.delta), eta = fe_from_u32<P>(pc.eta);
         const F ry = fe_mul(r, y);
-        const F rcbsca = fe_add(fe_mul(ry, b0), fe_mul(fe_mul(sc, y), a0));
-        pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 0) * 8, rcbsca);
-        pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 1) * 8, delta);
-        pb_st_canon<P>(vpB + (size_t)fixed_term_index(s, 0) * 8, fe_mul(ry, sc));
-        pb_st_canon<P>(vpB + (size_t)fixed_term_index(s, 1) * 8, eta);
+        if (phase != PB_POST) {
+            const F rcbsca = fe_add(fe_mul(ry, b0), fe_mul(fe_mul(sc, y), a0));
+            pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 0) * 8, rcbsca);
+            pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 1) * 8, delta);
+            pb_st_canon<P>(vpB + (size_t)fixed_term_index(s, 0) * 8, fe_mul(ry, sc));
+            pb_st_canon<P>(vpB + (size_t)fixed_term_index(s, 1) * 8, eta);
+        }
+        if (phase == PB_PRE) return;
+        const F ef = pb_ld<P>(consts + 4 * 8);
         uint32_t* o = out_scalars + p * 24;
         pb_st_canon<P>(o, fe_add(r, fe_mul(a0, ef)));
         pb_st_canon<P>(o + 8, fe_add(sc, fe_mul(b0, ef)));
@@ -316,20 +357,20 @@ __global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc
     }
 }
 
-// One lane per virtual proof: sums its `per` jacobian partials, converts to affine, writes the wire point at
-// its place in the proof record: out_points[p][3+2k] = [A, wip.A, wip.B, L.., R..] and out_V[p][m].
+// One lane per virtual proof of the launch (sel.cnt per real proof, starting at virtual proof sel.first): sums its
+// `per` jacobian partials, converts to affine, writes the wire point at its place in the proof record:
+// out_points[p][3+2k] = [A, wip.A, wip.B, L.., R..] and out_V[p][m].
 template <class C>
-__global__ void __launch_bounds__(64) k_pb_collect(VerifyShape s, const uint32_t* __restrict__ partials, uint32_t per,
-                                                   uint32_t* __restrict__ out_points, uint32_t* __restrict__ out_V,
-                                                   size_t nvp_total) {
+__global__ void __launch_bounds__(64) k_pb_collect(VerifyShape s, VpSel sel, const uint32_t* __restrict__ partials,
+                                                   uint32_t per, uint32_t* __restrict__ out_points,
+                                                   uint32_t* __restrict__ out_V, size_t nvp_total) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     constexpr int WW = 2 * N + 2;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nvp_total) return;
-    const uint32_t nvp = pb_num_vps(s.k, s.m);
-    const size_t p = g / nvp;
-    const uint32_t v = (uint32_t)(g % nvp);
+    const size_t p = g / sel.cnt;
+    const uint32_t v = sel.first + (uint32_t)(g % sel.cnt);
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(partials + (g * per + t) * JW));
     uint32_t w[WW];
@@ -348,6 +389,82 @@ __global__ void __launch_bounds__(64) k_pb_collect(VerifyShape s, const uint32_t
     }
 #pragma unroll
     for (int t = 0; t < WW; t++) dst[t] = w[t];
+}
+
+// ---- Fiat-Shamir steps of the batched prover (transcript.hpp), one lane per proof -------------------------------
+// tr_st: [count][8] running transcript states ; ch: [count][3 + k][8] the challenge block [y, z, e, e_1..e_k]
+// (canonical) -- the same block the verifier derives (bpp_verifier_derive_challenges).
+
+// after A and the commitments exist: V_0.., A -> y, z ; then the argument's separator
+template <class C>
+__global__ void __launch_bounds__(64) k_pb_fs_yz(VerifyShape s, TranscriptState st0, const uint32_t* __restrict__ out_points,
+                                                 const uint32_t* __restrict__ out_V, uint32_t* __restrict__ tr_st,
+                                                 uint32_t* __restrict__ ch, size_t count) {
+    using P = typename C::Fr;
+    constexpr uint32_t WW = 2 * C::Fp::N + 2;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    Transcript t;
+    for (int i = 0; i < 8; i++) t.st[i] = st0.st[i];
+    for (uint32_t j = 0; j < s.m; j++) tr_append_words(t, tr_tag('V'), out_V + (p * s.m + j) * WW, WW);
+    tr_append_words(t, tr_tag('A'), out_points + p * (size_t)(3 + 2 * s.k) * WW, WW);
+    uint32_t w[8];
+    uint32_t* c = ch + p * (size_t)(3 + s.k) * 8;
+    fe_to_canonical(tr_challenge<P>(t, tr_tag('y')), w);
+    for (int i = 0; i < 8; i++) c[i] = w[i];
+    fe_to_canonical(tr_challenge<P>(t, tr_tag('z')), w);
+    for (int i = 0; i < 8; i++) c[8 + i] = w[i];
+    const uint32_t dsep[2] = {tr_tag('w', 'i', 'p', 'p'), tr_tag(' ', 'v', '1', 0)};
+    tr_append_words(t, tr_tag('d', 's', 'e', 'p'), dsep, 2);
+    tr_append_u64(t, tr_tag('n'), s.mn);
+    for (int i = 0; i < 8; i++) tr_st[p * 8 + i] = t.st[i];
+}
+
+// after L_t, R_t exist: e_t and its inverse into the proof's constants block
+template <class C>
+__global__ void __launch_bounds__(64) k_pb_fs_round(VerifyShape s, uint32_t t, const uint32_t* __restrict__ out_points,
+                                                    uint32_t* __restrict__ tr_st, uint32_t* __restrict__ ch,
+                                                    uint32_t* __restrict__ st_consts, size_t count) {
+    using P = typename C::Fr;
+    constexpr uint32_t WW = 2 * C::Fp::N + 2;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t k = s.k;
+    Transcript tr;
+    for (int i = 0; i < 8; i++) tr.st[i] = tr_st[p * 8 + i];
+    const uint32_t* rec = out_points + p * (size_t)(3 + 2 * k) * WW;
+    tr_append_words(tr, tr_tag('L'), rec + (size_t)(3 + t) * WW, WW);
+    tr_append_words(tr, tr_tag('R'), rec + (size_t)(3 + k + t) * WW, WW);
+    const Fe<P> e = tr_challenge<P>(tr, tr_tag('e'));
+    for (int i = 0; i < 8; i++) tr_st[p * 8 + i] = tr.st[i];
+    uint32_t w[8];
+    fe_to_canonical(e, w);
+    for (int i = 0; i < 8; i++) ch[(p * (3 + k) + 3 + t) * 8 + i] = w[i];
+    uint32_t* consts = st_consts + p * (size_t)pb_consts_elems(k) * 8;
+    pb_st<P>(consts + (size_t)(5 + t) * 8, e);
+    pb_st<P>(consts + (size_t)(5 + k + t) * 8, fe_inv(e));
+}
+
+// after wip.A, wip.B exist: the final challenge e
+template <class C>
+__global__ void __launch_bounds__(64) k_pb_fs_final(VerifyShape s, const uint32_t* __restrict__ out_points,
+                                                    uint32_t* __restrict__ tr_st, uint32_t* __restrict__ ch,
+                                                    uint32_t* __restrict__ st_consts, size_t count) {
+    using P = typename C::Fr;
+    constexpr uint32_t WW = 2 * C::Fp::N + 2;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const uint32_t k = s.k;
+    Transcript tr;
+    for (int i = 0; i < 8; i++) tr.st[i] = tr_st[p * 8 + i];
+    const uint32_t* rec = out_points + p * (size_t)(3 + 2 * k) * WW;
+    tr_append_words(tr, tr_tag('w', 'A'), rec + (size_t)1 * WW, WW);
+    tr_append_words(tr, tr_tag('w', 'B'), rec + (size_t)2 * WW, WW);
+    const Fe<P> e = tr_challenge<P>(tr, tr_tag('e'));
+    uint32_t w[8];
+    fe_to_canonical(e, w);
+    for (int i = 0; i < 8; i++) ch[(p * (3 + k) + 2) * 8 + i] = w[i];
+    pb_st<P>(st_consts + p * (size_t)pb_consts_elems(k) * 8 + 4 * 8, e);
 }
 
 }  // namespace bpp

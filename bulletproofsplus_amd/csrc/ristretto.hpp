@@ -1,0 +1,182 @@
+// ristretto.hpp -- ristretto255 (RFC 9496) on the engine's edwards25519 instantiation: the prime-order group the
+// north star names ("curve25519/Ristretto"), at the boundary of the third backend.
+//
+// The reference has NO Ristretto code (a stale README example imports curve25519_dalek,
+// README.md:24-57, and nothing else) -- PARITY UNPINNED.  What is here follows RFC 9496 section 4 (decode 4.3.1,
+// encode 4.3.2, equality 4.3.3, element derivation 4.3.4) and is pinned by: the RFC's field constants (checked by
+// their defining identities in tools/gen_constants.py), the standard encoding of the base point
+// (e2f2ae0a...2d76, which a wrong implementation cannot reproduce by accident), encode/decode round trips, the group
+// law on encodings, and the big-integer restatement in oracle/pyref.py.
+//
+// Internally a ristretto255 element is carried as an edwards25519 point of the even subgroup 2E -- any
+// representative of its coset P + E[4].  Consequences for the engine:
+//   * decoding yields a representative that may differ from the prime-order one by a 4-torsion point, so a sum that
+//     is the identity of the quotient group lands in E[4] = {(0, 1), (0, -1), (+-i, 0)}: the verdict test for this
+//     curve is "x = 0 or y = 0" (ed_is_identity_class), which coincides with the exact test on prime-order inputs;
+//   * two points are the same element iff x1 y2 = y1 x2 or y1 y2 = x1 x2 (rist_equal).
+#pragma once
+#include "ed25519.hpp"
+
+namespace bpp {
+
+namespace rist {
+using F = Fe<EdFp>;
+
+BPP_HD F k(const uint32_t* c) { return ed::konst(c); }
+
+// canonical value odd?  (IS_NEGATIVE of RFC 9496 4.1)
+BPP_HD bool is_negative(const F& a) {
+    uint32_t w[8];
+    fe_to_canonical(a, w);
+    return (w[0] & 1u) != 0;
+}
+BPP_HD F select(bool c, const F& a, const F& b) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < EdFp::NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+BPP_HD F abs(const F& a) { return select(is_negative(a), fe_neg(a), a); }
+
+// a^((p - 5) / 8)
+BPP_HD F pow_p58(const F& a) {
+    F acc = F::one();
+    bool started = false;
+    for (int i = 255; i >= 0; i--) {
+        if (started) acc = fe_sqr(acc);
+        if ((Ed25519Consts::P58W[i >> 5] >> (i & 31)) & 1u) {
+            acc = started ? fe_mul(acc, a) : a;
+            started = true;
+        }
+    }
+    return acc;
+}
+
+// SQRT_RATIO_M1(u, v) of RFC 9496 4.2: (was_square, r) with r = sqrt(u / v) when u / v is a square, else
+// sqrt(SQRT_M1 * u / v); r is the non-negative root
+BPP_HD bool sqrt_ratio_m1(const F& u, const F& v, F& r) {
+    const F sqrt_m1 = k(Ed25519Consts::SQRT_M1);
+    const F v3 = fe_mul(fe_sqr(v), v);
+    const F v7 = fe_mul(fe_sqr(v3), v);
+    r = fe_mul(fe_mul(u, v3), pow_p58(fe_mul(u, v7)));
+    const F check = fe_mul(v, fe_sqr(r));
+    const F neg_u = fe_neg(u);
+    const bool correct_sign = check == u;
+    const bool flipped = check == neg_u;
+    const bool flipped_i = check == fe_mul(neg_u, sqrt_m1);
+    const F r_prime = fe_mul(sqrt_m1, r);
+    r = select(flipped || flipped_i, r_prime, r);
+    r = abs(r);
+    return correct_sign || flipped;
+}
+}  // namespace rist
+
+// 32 bytes -> a representative point (affine; x, y with t = x y >= 0 as the RFC fixes them).  false: not a canonical
+// encoding of a ristretto255 element.
+BPP_HD bool rist_decode(const uint8_t* s, Aff<Ed25519>& out) {
+    using namespace rist;
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) | ((uint32_t)s[4 * i + 3] << 24);
+    if (!words_lt_mod<EdFp>(w)) return false;     // non-canonical field encoding
+    if (w[0] & 1u) return false;                  // s must be non-negative
+    const F sv = fe_from_canonical<EdFp>(w);
+    const F one = F::one();
+    const F ss = fe_sqr(sv);
+    const F u1 = fe_sub(one, ss), u2 = fe_add(one, ss);
+    const F u2_sqr = fe_sqr(u2);
+    const F v = fe_sub(fe_neg(fe_mul(k(Ed25519Consts::D), fe_sqr(u1))), u2_sqr);
+    F invsqrt;
+    const bool was_square = sqrt_ratio_m1(one, fe_mul(v, u2_sqr), invsqrt);
+    const F den_x = fe_mul(invsqrt, u2);
+    const F den_y = fe_mul(fe_mul(invsqrt, den_x), v);
+    const F x = abs(fe_mul(fe_dbl(sv), den_x));
+    const F y = fe_mul(u1, den_y);
+    const F t = fe_mul(x, y);
+    if (!was_square || is_negative(t) || y.is_zero()) return false;
+    out.x = x;
+    out.y = y;
+    return true;
+}
+
+// a point of the even subgroup (extended coordinates X, Y, Z, T) -> the 32-byte encoding of its coset
+BPP_HD void rist_encode(const Jac<Ed25519>& p, uint8_t* out) {
+    using namespace rist;
+    const F u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
+    const F u2 = fe_mul(p.X, p.Y);
+    F invsqrt;
+    (void)sqrt_ratio_m1(F::one(), fe_mul(u1, fe_sqr(u2)), invsqrt);
+    const F den1 = fe_mul(invsqrt, u1), den2 = fe_mul(invsqrt, u2);
+    const F z_inv = fe_mul(fe_mul(den1, den2), p.T);
+    const F sqrt_m1 = k(Ed25519Consts::SQRT_M1);
+    const F ix0 = fe_mul(p.X, sqrt_m1), iy0 = fe_mul(p.Y, sqrt_m1);
+    const F ench = fe_mul(den1, k(Ed25519Consts::INVSQRT_A_MINUS_D));
+    const bool rotate = is_negative(fe_mul(p.T, z_inv));
+    const F x = select(rotate, iy0, p.X);
+    F y = select(rotate, ix0, p.Y);
+    const F den_inv = select(rotate, ench, den2);
+    if (is_negative(fe_mul(x, z_inv))) y = fe_neg(y);
+    const F sv = abs(fe_mul(den_inv, fe_sub(p.Z, y)));
+    uint32_t w[8];
+    fe_to_canonical(sv, w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        out[4 * i] = (uint8_t)w[i];
+        out[4 * i + 1] = (uint8_t)(w[i] >> 8);
+        out[4 * i + 2] = (uint8_t)(w[i] >> 16);
+        out[4 * i + 3] = (uint8_t)(w[i] >> 24);
+    }
+}
+
+// same ristretto255 element?  (RFC 9496 4.3.3, on affine representatives)
+BPP_HD bool rist_equal(const Aff<Ed25519>& a, const Aff<Ed25519>& b) {
+    return fe_mul(a.x, b.y) == fe_mul(a.y, b.x) || fe_mul(a.y, b.y) == fe_mul(a.x, b.x);
+}
+
+// the identity of the quotient group: a point of E[4], x = 0 or y = 0
+BPP_HD bool ed_is_identity_class(const Jac<Ed25519>& p) { return p.X.is_zero() || p.Y.is_zero(); }
+
+// MAP of RFC 9496 4.3.4 (the Elligator-2 based one-way map) on a field element t
+BPP_HD Jac<Ed25519> rist_map(const Fe<EdFp>& t) {
+    using namespace rist;
+    const F one = F::one();
+    const F d = k(Ed25519Consts::D);
+    const F r = fe_mul(k(Ed25519Consts::SQRT_M1), fe_sqr(t));
+    const F u = fe_mul(fe_add(r, one), k(Ed25519Consts::ONE_MINUS_D_SQ));
+    const F v = fe_mul(fe_sub(fe_neg(one), fe_mul(r, d)), fe_add(r, d));
+    F s;
+    const bool was_square = sqrt_ratio_m1(u, v, s);
+    const F s_prime = fe_neg(abs(fe_mul(s, t)));
+    s = select(was_square, s, s_prime);
+    const F c = select(was_square, fe_neg(one), r);
+    const F N = fe_sub(fe_mul(fe_mul(c, fe_sub(r, one)), k(Ed25519Consts::D_MINUS_ONE_SQ)), v);
+    const F w0 = fe_mul(fe_dbl(s), v);
+    const F w1 = fe_mul(N, k(Ed25519Consts::SQRT_AD_MINUS_ONE));
+    const F ssq = fe_sqr(s);
+    const F w2 = fe_sub(one, ssq), w3 = fe_add(one, ssq);
+    Jac<Ed25519> p;
+    p.X = fe_mul(w0, w3);
+    p.Y = fe_mul(w2, w1);
+    p.Z = fe_mul(w1, w3);
+    p.T = fe_mul(w0, w2);
+    return p;
+}
+
+// element derivation from 64 uniform bytes: MAP(t1) + MAP(t2), t_i = the 32-byte halves with the top bit masked,
+// read little-endian and reduced mod p
+BPP_HD Jac<Ed25519> rist_from_uniform_bytes(const uint8_t* b) {
+    Jac<Ed25519> pts[2];
+    for (int h = 0; h < 2; h++) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            w[i] = (uint32_t)b[32 * h + 4 * i] | ((uint32_t)b[32 * h + 4 * i + 1] << 8) | ((uint32_t)b[32 * h + 4 * i + 2] << 16) |
+                   ((uint32_t)b[32 * h + 4 * i + 3] << 24);
+        w[7] &= 0x7fffffffu;
+        pts[h] = rist_map(fe_from_canonical<EdFp>(w));   // fe_from_canonical reduces values in [p, 2^255)
+    }
+    return jac_add(pts[0], pts[1]);
+}
+
+}  // namespace bpp

@@ -199,6 +199,14 @@ int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n,
  * bpp_range_prove_batch_device. */
 int bpp_verifier_derive_challenges(bpp_verifier *v, const uint64_t *d_points, size_t count, uint64_t *d_challenges,
                                    void *stream);
+/* host buffers, as bpp_range_prove_batch */
+int bpp_range_prove_batch_fs(bpp_verifier *engine, const uint64_t *v, const uint64_t *gamma, size_t count,
+                             uint64_t *out_points, uint64_t *out_scalars, uint64_t *out_V);
+/* device buffers, as bpp_range_prove_batch_device; d_out_challenges: count x (3 + k) scalars [y, z, e, e_1..e_k] the
+ * prover drew (may be NULL) */
+int bpp_range_prove_batch_fs_device(bpp_verifier *engine, const uint64_t *d_v, const uint64_t *d_gamma, size_t count,
+                                    uint64_t *d_out_points, uint64_t *d_out_scalars, uint64_t *d_out_V,
+                                    uint64_t *d_out_challenges, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* Per-stage timing with HIP events recorded on the caller's stream around the kernels of a pass
  * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant; its first blocks also run

@@ -976,3 +976,117 @@ def prove_case(curve_name: str, n: int, values, gammas, shadow=True, trace=None)
         prover.commit(pk, v, gm % G.r)
     proof = RangeProof.prove(pk, n, prover, trace)
     return pk, prover, proof
+
+
+# --------------------------------------------------------------------------------------
+# ristretto255 (RFC 9496 section 4) -- TEST ORACLE for bulletproofsplus_amd/csrc/ristretto.hpp.  The reference has no
+# Ristretto code; this follows the RFC's pseudocode over Python integers.
+# --------------------------------------------------------------------------------------
+class Ristretto255:
+    P = (1 << 255) - 19
+    D = (-121665 * pow(121666, -1, P)) % P
+    SQRT_M1 = 19681161376707505956807079304988542015446066515923890162744021073123829784752
+    SQRT_AD_MINUS_ONE = 25063068953384623474111414158702152701244531502492656460079210482610430750235
+    INVSQRT_A_MINUS_D = 54469307008909316920995813868745141605393597292927456921205312896311721017578
+    ONE_MINUS_D_SQ = (1 - D * D) % P
+    D_MINUS_ONE_SQ = (D - 1) ** 2 % P
+    BASE_ENCODING = bytes.fromhex("e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76")
+
+    @classmethod
+    def is_neg(cls, x):
+        return (x % cls.P) & 1
+
+    @classmethod
+    def ct_abs(cls, x):
+        x %= cls.P
+        return (-x) % cls.P if x & 1 else x
+
+    @classmethod
+    def sqrt_ratio_m1(cls, u, v):
+        p = cls.P
+        v3 = v * v * v % p
+        v7 = v3 * v3 * v % p
+        r = u * v3 * pow(u * v7, (p - 5) // 8, p) % p
+        check = v * r * r % p
+        correct = check == u % p
+        flipped = check == (-u) % p
+        flipped_i = check == (-u) * cls.SQRT_M1 % p
+        if flipped or flipped_i:
+            r = cls.SQRT_M1 * r % p
+        return (correct or flipped), cls.ct_abs(r)
+
+    @classmethod
+    def decode(cls, b: bytes):
+        """-> (x, y) representative or None"""
+        p = cls.P
+        s = int.from_bytes(b, "little")
+        if s >= p or s & 1:
+            return None
+        ss = s * s % p
+        u1, u2 = (1 - ss) % p, (1 + ss) % p
+        u2s = u2 * u2 % p
+        v = (-(cls.D * u1 * u1) - u2s) % p
+        ok, inv = cls.sqrt_ratio_m1(1, v * u2s % p)
+        den_x = inv * u2 % p
+        den_y = inv * den_x * v % p
+        x = cls.ct_abs(2 * s * den_x)
+        y = u1 * den_y % p
+        t = x * y % p
+        if not ok or t & 1 or y == 0:
+            return None
+        return (x, y)
+
+    @classmethod
+    def encode(cls, P_) -> bytes:
+        """affine (x, y) of the even subgroup (None = the identity (0, 1)) -> 32 bytes"""
+        p = cls.P
+        x0, y0 = (0, 1) if P_ is None else P_
+        z0, t0 = 1, x0 * y0 % p
+        u1 = (z0 + y0) * (z0 - y0) % p
+        u2 = x0 * y0 % p
+        _, inv = cls.sqrt_ratio_m1(1, u1 * u2 * u2 % p)
+        den1, den2 = inv * u1 % p, inv * u2 % p
+        z_inv = den1 * den2 * t0 % p
+        ix0, iy0 = x0 * cls.SQRT_M1 % p, y0 * cls.SQRT_M1 % p
+        ench = den1 * cls.INVSQRT_A_MINUS_D % p
+        rotate = cls.is_neg(t0 * z_inv)
+        x, y, den_inv = (iy0, ix0, ench) if rotate else (x0, y0, den2)
+        if cls.is_neg(x * z_inv):
+            y = (-y) % p
+        return cls.ct_abs(den_inv * (z0 - y)).to_bytes(32, "little")
+
+    @classmethod
+    def equal(cls, A, B):
+        p = cls.P
+        A = (0, 1) if A is None else A
+        B = (0, 1) if B is None else B
+        return (A[0] * B[1] - A[1] * B[0]) % p == 0 or (A[1] * B[1] - A[0] * B[0]) % p == 0
+
+    @classmethod
+    def map(cls, t):
+        """MAP of RFC 9496 4.3.4 -> extended (X, Y, Z, T)"""
+        p = cls.P
+        r = cls.SQRT_M1 * t * t % p
+        u = (r + 1) * cls.ONE_MINUS_D_SQ % p
+        v = (-1 - r * cls.D) * (r + cls.D) % p
+        ok, s = cls.sqrt_ratio_m1(u, v)
+        s_prime = (-cls.ct_abs(s * t)) % p
+        s = s if ok else s_prime
+        c = (p - 1) if ok else r
+        N = (c * (r - 1) * cls.D_MINUS_ONE_SQ - v) % p
+        w0 = 2 * s * v % p
+        w1 = N * cls.SQRT_AD_MINUS_ONE % p
+        w2, w3 = (1 - s * s) % p, (1 + s * s) % p
+        return (w0 * w3 % p, w2 * w1 % p, w1 * w3 % p, w0 * w2 % p)
+
+    @classmethod
+    def from_uniform_bytes(cls, b: bytes, G):
+        """64 bytes -> affine point (G: EdwardsGroup for the addition)"""
+        p = cls.P
+        out = []
+        for h in range(2):
+            t = int.from_bytes(b[32 * h:32 * h + 32], "little") & ((1 << 255) - 1)
+            X, Y, Z, _ = cls.map(t % p)
+            zi = pow(Z, -1, p)
+            out.append((X * zi % p, Y * zi % p))
+        return G.add(out[0], out[1])

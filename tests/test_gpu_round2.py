@@ -264,3 +264,100 @@ def test_length_mismatches_raise():
     with pytest.raises(RuntimeError):
         bv.verify_wire(np.stack([rec, rec]), proof.scalars_wire()[None])
     bv.close()
+
+
+@pytest.mark.parametrize("cname,cid,n,vals,gams,c", [
+    ("secp256k1", 1, 8, [200, 5], [3, 7], 5),
+    ("bls12_381", 0, 8, [77], [9], 4),
+    ("bls12_381", 0, 4, [9, 3, 15, 0], [1, 2, 3, 4], 6),
+])
+def test_fs_prover_small_bit_exact(cname, cid, n, vals, gams, c):
+    """The batched prover under the Fiat-Shamir transcript == the C oracle's transcript-mode prover, bit for bit, and
+    the challenges it drew == the ones the verifier derives from the proof."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    m = len(vals)
+    a = B.Arith.init(cname)
+    opk = O.PublicKey(cid, n * m)
+    pk = B.PublicKey.from_points(a, opk.gh, opk.G, opk.H)
+    bv = B.BatchVerifier(pk, n, m, window_bits=c)
+    O.set_transcript(True)
+    try:
+        opts, osc, oV = O.range_prove(opk, n, vals, gams)
+        rc, _, _, och = O.range_verify(opk, n, m, opts, osc, oV, want_challenges=True)
+        assert rc == 0
+    finally:
+        O.set_transcript(False)
+    vals2 = [[(v + 1) % (1 << n) for v in vals], vals]           # a second, different proof in the batch
+    gams2 = [[g + 5 for g in gams], gams]
+    pts, scs, V = bv.prove_batch(vals2, gams2, transcript=True)
+    assert np.array_equal(pts[1], opts) and np.array_equal(scs[1], osc) and np.array_equal(V[1], oV)
+    recs = np.ascontiguousarray(np.concatenate([pts, V], axis=1))
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(recs.view(np.int64)).to(dev)
+    d_ch = torch.zeros((2, 3 + bv.k, 4), dtype=torch.int64, device=dev)
+    bv.derive_challenges_device(d_pts.data_ptr(), 2, d_ch.data_ptr())
+    torch.cuda.synchronize()
+    ch = d_ch.cpu().numpy().view(np.uint64)
+    assert np.array_equal(ch[1], och)
+    ok, _, _ = run_verifier_device(torch, bv, recs, scs, want_scalars=False, want_result=False, challenges=ch)
+    assert ok.tolist() == [0, 0]
+    bad = scs.copy()
+    bad[0, 2, 0] ^= np.uint64(1)
+    ok, _, _ = run_verifier_device(torch, bv, recs, bad, want_scalars=False, want_result=False, challenges=ch)
+    assert ok.tolist() == [1, 0]
+    # the constants-mode prover of the same engine is untouched by the transcript code path
+    cpts, csc, cV = O.range_prove(opk, n, vals, gams)
+    pts_c, scs_c, V_c = bv.prove_batch([vals], [gams])
+    assert np.array_equal(pts_c[0], cpts) and np.array_equal(scs_c[0], csc) and np.array_equal(V_c[0], cV)
+    bv.close()
+
+
+def test_fs_prover_reference_size_64x16():
+    """(64,16) under the transcript: device-resident prover (challenge block returned) -> the oracle's transcript-mode
+    verifier accepts proof 0 and derives the same challenges; the device verifier accepts all, rejects a tampered one."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    n, m, count = 64, 16, 6
+    a = B.Arith.init("bls12_381")
+    opk = O.PublicKey(O.BLS12_381, n * m)
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=10)
+    k = bv.k
+    dev = torch.device("cuda:0")
+    vals = np.array([_values(3 + 17 * d, m)[0] for d in range(count)], dtype=np.uint64)
+    gam = np.zeros((count, m, 4), dtype=np.uint64)
+    for d in range(count):
+        gam[d, :, 0] = np.array(_values(3 + 17 * d, m)[1], dtype=np.uint64)
+    d_v = torch.from_numpy(vals.view(np.int64)).to(dev)
+    d_g = torch.from_numpy(gam.view(np.int64)).to(dev)
+    d_po = torch.zeros((count, 3 + 2 * k, a.PW), dtype=torch.int64, device=dev)
+    d_ps = torch.zeros((count, 3, 4), dtype=torch.int64, device=dev)
+    d_pV = torch.zeros((count, m, a.PW), dtype=torch.int64, device=dev)
+    d_ch = torch.zeros((count, 3 + k, 4), dtype=torch.int64, device=dev)
+    wsb = bv.prover_workspace_bytes(count)
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    bv.prove_batch_device(d_v.data_ptr(), d_g.data_ptr(), count, d_po.data_ptr(), d_ps.data_ptr(), d_pV.data_ptr(),
+                          d_ws.data_ptr(), wsb, transcript=True, d_out_challenges=d_ch.data_ptr())
+    torch.cuda.synchronize()
+    pts = d_po.cpu().numpy().view(np.uint64)
+    scs = d_ps.cpu().numpy().view(np.uint64)
+    V = d_pV.cpu().numpy().view(np.uint64)
+    ch = d_ch.cpu().numpy().view(np.uint64)
+    O.set_transcript(True)
+    try:
+        rc, _, _, och = O.range_verify(opk, n, m, pts[0], scs[0], V[0], want_challenges=True)
+    finally:
+        O.set_transcript(False)
+    assert rc == 0 and np.array_equal(ch[0], och)
+    recs = np.ascontiguousarray(np.concatenate([pts, V], axis=1))
+    d_rec = torch.from_numpy(recs.view(np.int64)).to(dev)
+    d_ch2 = torch.zeros_like(d_ch)
+    bv.derive_challenges_device(d_rec.data_ptr(), count, d_ch2.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ch2.cpu().numpy().view(np.uint64), ch)
+    bad = scs.copy()
+    bad[4, 0, 0] ^= np.uint64(2)
+    ok, _, _ = run_verifier_device(torch, bv, recs, bad, want_scalars=False, want_result=False, challenges=ch)
+    assert ok.tolist() == [0, 0, 0, 0, 1, 0]
+    bv.close()
