@@ -22,6 +22,7 @@ FP_LIMBS = {BLS12_381_G1: 6, SECP256K1: 4, ED25519: 4}
 
 OK = 0
 VERIFICATION_ERROR = 1
+FORMAT_ERROR = 2   # ProofError::FormatError (reference src/errors.rs:20)
 
 # every symbol include/bpp_amd.h declares (tests check that the library exports all of them)
 EXPORTS = [
@@ -34,7 +35,8 @@ EXPORTS = [
     "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
     "bpp_verifier_derive_challenges", "bpp_range_prove_batch_fs", "bpp_range_prove_batch_fs_device",
     "bpp_point_compressed_bytes", "bpp_points_compress", "bpp_points_decompress", "bpp_points_decompress_device",
-    "bpp_range_verify_batch_compressed",
+    "bpp_range_verify_batch_compressed", "bpp_proof_bytes", "bpp_proofs_encode", "bpp_proofs_decode",
+    "bpp_range_verify_batch_serialized",
 ]
 
 
@@ -104,6 +106,11 @@ def lib():
         L.bpp_points_decompress.argtypes = [vp, vp, sz, vp, vp]
         L.bpp_points_decompress_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.bpp_range_verify_batch_compressed.argtypes = [vp, vp, vp, sz, vp]
+        L.bpp_proof_bytes.argtypes = [i32, sz, sz]
+        L.bpp_proof_bytes.restype = sz
+        L.bpp_proofs_encode.argtypes = [vp, sz, sz, vp, vp, sz, vp]
+        L.bpp_proofs_decode.argtypes = [vp, sz, sz, vp, sz, vp, vp, vp]
+        L.bpp_range_verify_batch_serialized.argtypes = [vp, vp, vp, sz, i32, vp]
         L.bpp_debug_field_op.argtypes = [vp, i32, i32, vp, vp, sz, vp]
         L.bpp_debug_point_op.argtypes = [vp, i32, vp, vp, sz, vp]
         _lib = L

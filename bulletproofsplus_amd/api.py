@@ -190,6 +190,39 @@ def decompress_points(arith: Arith, data):
     return pts, ok
 
 
+def proof_bytes(arith: Arith, n: int, m: int) -> int:
+    """bytes of one serialized proof (include/bpp_amd.h, "the container")"""
+    return _lib.lib().bpp_proof_bytes(arith.curve, n, m)
+
+
+def encode_proofs(arith: Arith, n: int, m: int, points, scalars) -> np.ndarray:
+    """points (count, 3+2k, PW), scalars (count, 3, 4) -> (count, proof_bytes) u8.  No reference counterpart."""
+    k = (n * m).bit_length() - 1
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3 + 2 * k, arith.PW)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
+    if sc.shape[0] != pts.shape[0]:
+        raise RuntimeError("encode_proofs: one scalar triple per proof")
+    out = np.zeros((pts.shape[0], proof_bytes(arith, n, m)), dtype=np.uint8)
+    check(_lib.lib().bpp_proofs_encode(arith.handle, n, m, _ptr(pts), _ptr(sc), pts.shape[0], _ptr(out)), "bpp_proofs_encode")
+    return out
+
+
+def decode_proofs(arith: Arith, n: int, m: int, data):
+    """(count, proof_bytes) u8 -> (points, scalars, status); status 0 valid / 2 FormatError"""
+    k = (n * m).bit_length() - 1
+    raw = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, proof_bytes(arith, n, m))
+    count = raw.shape[0]
+    pts = np.zeros((count, 3 + 2 * k, arith.PW), dtype=np.uint64)
+    sc = np.zeros((count, 3, 4), dtype=np.uint64)
+    st = np.zeros(count, dtype=np.uint32)
+    check(_lib.lib().bpp_proofs_decode(arith.handle, n, m, _ptr(raw), count, _ptr(pts), _ptr(sc), _ptr(st)), "bpp_proofs_decode")
+    return pts, sc, st
+
+
+class FormatError(ProofError):
+    """ProofError::FormatError (reference src/errors.rs:20): a serialized proof that does not parse"""
+
+
 class PublicKey:
     """reference publickey.rs:13-52.  Fields g, h, G_vec, H_vec as in the reference."""
 
@@ -407,6 +440,20 @@ class BatchVerifier:
         ok = np.zeros(count, dtype=np.uint32)
         check(_lib.lib().bpp_range_verify_batch_compressed(self.handle, _ptr(rec), _ptr(sc), count, _ptr(ok)),
               "bpp_range_verify_batch_compressed")
+        return ok
+
+    def verify_serialized(self, proofs, commitments, transcript: bool = False) -> np.ndarray:
+        """proofs (count, proof_bytes) u8, commitments (count, m, compressed_bytes) u8 -> status (count,) u32:
+        0 Ok / 1 VerificationError / 2 FormatError"""
+        pb = proof_bytes(self.arith, self.n, self.m)
+        raw = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1, pb)
+        cm = np.ascontiguousarray(commitments, dtype=np.uint8).reshape(-1, self.m, compressed_bytes(self.arith))
+        if cm.shape[0] != raw.shape[0]:
+            raise RuntimeError("verify_serialized: m commitments per proof")
+        ok = np.zeros(raw.shape[0], dtype=np.uint32)
+        check(_lib.lib().bpp_range_verify_batch_serialized(self.handle, _ptr(raw), _ptr(cm), raw.shape[0],
+                                                           1 if transcript else 0, _ptr(ok)),
+              "bpp_range_verify_batch_serialized")
         return ok
 
     def run_device(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,

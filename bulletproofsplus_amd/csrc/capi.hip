@@ -313,6 +313,7 @@ extern "C" size_t bpp_point_compressed_bytes(int curve_id) {
     switch (curve_id) {
         case BPP_BLS12_381_G1: return 48;
         case BPP_SECP256K1: return 33;
+        case BPP_ED25519: return 32;   /* ristretto255 */
         default: return 0;
     }
 }
@@ -386,6 +387,168 @@ extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t*
         }
         return BPP_OK;
     });
+    return BPP_OK;
+}
+
+// ---- serialized proofs (the container; see include/bpp_amd.h) -----------------------------------------------------
+namespace {
+constexpr size_t BPP_HDR = 12;   // "BPP+" | version | curve | n | m | k | 3 reserved zero bytes
+inline uint32_t log2_exact(size_t x) {
+    uint32_t k = 0;
+    while (((size_t)1 << k) < x) k++;
+    return k;
+}
+// canonical (< group order) 32-byte little-endian scalar?
+inline bool scalar_is_canonical(int curve, const uint8_t* b) {
+    bool lt = false;
+    dispatch(curve, [&](auto cv) -> int {
+        using Fr = typename decltype(cv)::Fr;
+        uint32_t w[8];
+        for (int i = 0; i < 8; i++)
+            w[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+        lt = words_lt_mod<Fr>(w);
+        return 0;
+    });
+    return lt;
+}
+}  // namespace
+
+extern "C" size_t bpp_proof_bytes(int curve_id, size_t n, size_t m) {
+    const size_t cb = bpp_point_compressed_bytes(curve_id);
+    const size_t mn = n * m;
+    if (cb == 0 || mn == 0 || (mn & (mn - 1))) return 0;
+    return BPP_HDR + (3 + 2 * (size_t)log2_exact(mn)) * cb + 96;
+}
+
+extern "C" int bpp_proofs_encode(bpp_ctx* ctx, size_t n, size_t m, const uint64_t* points, const uint64_t* scalars,
+                                 size_t count, uint8_t* out) {
+    if (!ctx || (count && (!points || !scalars || !out))) return fail(BPP_E_ARG, "null argument");
+    const size_t pb = bpp_proof_bytes(ctx->curve, n, m);
+    if (pb == 0 || n > 255 || m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255)");
+    if (count == 0) return BPP_OK;
+    const size_t cb = bpp_point_compressed_bytes(ctx->curve);
+    const uint32_t k = log2_exact(n * m);
+    const size_t npp = 3 + 2 * (size_t)k;
+    std::vector<uint8_t> comp(count * npp * cb);
+    int rc = bpp_points_compress(ctx, points, count * npp, comp.data());
+    if (rc) return rc;
+    for (size_t p = 0; p < count; p++) {
+        uint8_t* o = out + p * pb;
+        const uint8_t hdr[BPP_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)ctx->curve, (uint8_t)n, (uint8_t)m, (uint8_t)k, 0, 0, 0};
+        std::memcpy(o, hdr, BPP_HDR);
+        std::memcpy(o + BPP_HDR, comp.data() + p * npp * cb, npp * cb);
+        std::memcpy(o + BPP_HDR + npp * cb, scalars + p * 12, 96);   // little-endian host: the u64 limbs are the bytes
+    }
+    return BPP_OK;
+}
+
+// decode to device buffers: d_points count x (3 + 2k) wire points, status[p] = 0 / BPP_FORMAT_ERROR (host vector)
+static int proofs_decode_common(bpp_ctx* ctx, size_t n, size_t m, const uint8_t* in, size_t count, DevBuf& d_points,
+                                std::vector<uint64_t>& scalars, std::vector<uint32_t>& status) {
+    const size_t pb = bpp_proof_bytes(ctx->curve, n, m);
+    if (pb == 0 || n > 255 || m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255)");
+    const size_t cb = bpp_point_compressed_bytes(ctx->curve);
+    const uint32_t k = log2_exact(n * m);
+    const size_t npp = 3 + 2 * (size_t)k;
+    const size_t pw = (size_t)bpp_point_words(ctx->curve) * 8;
+    status.assign(count, 0);
+    scalars.assign(count * 12, 0);
+    std::vector<uint8_t> comp(count * npp * cb);
+    for (size_t p = 0; p < count; p++) {
+        const uint8_t* s = in + p * pb;
+        const uint8_t hdr[BPP_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)ctx->curve, (uint8_t)n, (uint8_t)m, (uint8_t)k, 0, 0, 0};
+        if (std::memcmp(s, hdr, BPP_HDR) != 0) status[p] = BPP_FORMAT_ERROR;   // magic, version, curve, shape, reserved
+        std::memcpy(comp.data() + p * npp * cb, s + BPP_HDR, npp * cb);
+        const uint8_t* sc = s + BPP_HDR + npp * cb;
+        for (int t = 0; t < 3; t++)
+            if (!scalar_is_canonical(ctx->curve, sc + 32 * t)) status[p] = BPP_FORMAT_ERROR;   // one encoding per scalar
+        std::memcpy(scalars.data() + p * 12, sc, 96);
+    }
+    DevBuf db, dk;
+    HIPCHK(db.alloc(count * npp * cb));
+    HIPCHK(dk.alloc(count * npp * 4));
+    HIPCHK(d_points.alloc(count * npp * pw));
+    HIPCHK(hipMemcpy(db.p, comp.data(), comp.size(), hipMemcpyHostToDevice));
+    int rc = dispatch(ctx->curve, [&](auto cv) -> int {
+        return CodecImpl<decltype(cv)>::decompress_device(static_cast<const uint8_t*>(db.p), count * npp,
+                                                          static_cast<uint64_t*>(d_points.p), dk.u32(), nullptr, true);
+    });
+    if (rc) return rc;
+    std::vector<uint32_t> bad(count * npp);
+    HIPCHK(hipMemcpy(bad.data(), dk.p, bad.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < bad.size(); i++)
+        if (bad[i]) status[i / npp] = BPP_FORMAT_ERROR;   // malformed encoding or a point outside the prime-order group
+    return BPP_OK;
+}
+
+extern "C" int bpp_proofs_decode(bpp_ctx* ctx, size_t n, size_t m, const uint8_t* in, size_t count, uint64_t* out_points,
+                                 uint64_t* out_scalars, uint32_t* out_status) {
+    if (!ctx || (count && (!in || !out_points || !out_scalars || !out_status))) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf dp;
+    std::vector<uint64_t> sc;
+    std::vector<uint32_t> st;
+    int rc = proofs_decode_common(ctx, n, m, in, count, dp, sc, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_points, dp.p, dp.bytes, hipMemcpyDeviceToHost));
+    std::memcpy(out_scalars, sc.data(), sc.size() * 8);
+    std::memcpy(out_status, st.data(), st.size() * 4);
+    return BPP_OK;
+}
+
+extern "C" int bpp_range_verify_batch_serialized(bpp_verifier* v, const uint8_t* proofs, const uint8_t* commitments,
+                                                 size_t count, int transcript, uint32_t* out_ok) {
+    if (!v || !proofs || !commitments || !out_ok) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    HIPCHK(hipSetDevice(v->ctx.device));
+    const VerifyShape& s = v->s;
+    const size_t cb = bpp_point_compressed_bytes(v->ctx.curve);
+    const size_t pw = (size_t)bpp_point_words(v->ctx.curve) * 8;
+    const size_t npp = 3 + 2 * (size_t)s.k;
+    DevBuf dproof;
+    std::vector<uint64_t> sc;
+    std::vector<uint32_t> st;
+    int rc = proofs_decode_common(&v->ctx, s.n, s.m, proofs, count, dproof, sc, st);
+    if (rc) return rc;
+    // the commitments, decoded with the same checks
+    DevBuf dcb, dck, dV, drec, dsc, dok, dws, dch;
+    HIPCHK(dcb.alloc(count * s.m * cb));
+    HIPCHK(dck.alloc(count * s.m * 4));
+    HIPCHK(dV.alloc(count * s.m * pw));
+    HIPCHK(hipMemcpy(dcb.p, commitments, count * s.m * cb, hipMemcpyHostToDevice));
+    rc = dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return CodecImpl<decltype(cv)>::decompress_device(static_cast<const uint8_t*>(dcb.p), count * s.m,
+                                                          static_cast<uint64_t*>(dV.p), dck.u32(), nullptr, true);
+    });
+    if (rc) return rc;
+    std::vector<uint32_t> badV(count * s.m);
+    HIPCHK(hipMemcpy(badV.data(), dck.p, badV.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < badV.size(); i++)
+        if (badV[i]) st[i / s.m] = BPP_FORMAT_ERROR;
+    // records [A, wip.A, wip.B, L.., R.., V..] per proof
+    HIPCHK(drec.alloc(count * s.NV * pw));
+    HIPCHK(hipMemcpy2D(drec.p, s.NV * pw, dproof.p, npp * pw, npp * pw, count, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy2D(static_cast<uint8_t*>(drec.p) + npp * pw, s.NV * pw, dV.p, s.m * pw, s.m * pw, count,
+                       hipMemcpyDeviceToDevice));
+    HIPCHK(dsc.alloc(count * 96));
+    HIPCHK(hipMemcpy(dsc.p, sc.data(), count * 96, hipMemcpyHostToDevice));
+    HIPCHK(dok.alloc(count * 4));
+    const size_t wsb = bpp_verifier_workspace_bytes(v, count);
+    HIPCHK(dws.alloc(wsb));
+    const uint64_t* d_ch = nullptr;
+    if (transcript) {
+        HIPCHK(dch.alloc(count * (size_t)(3 + s.k) * 32));
+        rc = bpp_verifier_derive_challenges(v, static_cast<const uint64_t*>(drec.p), count, static_cast<uint64_t*>(dch.p), nullptr);
+        if (rc) return rc;
+        d_ch = static_cast<const uint64_t*>(dch.p);
+    }
+    rc = bpp_verifier_run(v, static_cast<const uint64_t*>(drec.p), static_cast<const uint64_t*>(dsc.p), count, d_ch, dok.u32(),
+                          dws.p, wsb, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < count; p++)
+        if (st[p]) out_ok[p] = BPP_FORMAT_ERROR;   // ProofError::FormatError takes precedence over the MulVec verdict
     return BPP_OK;
 }
 

@@ -10,8 +10,13 @@
 //                  the lexicographically larger root (y > (p-1)/2)           [ZCash / IETF pairing-friendly curves]
 //   secp256k1    : 33 bytes, SEC1: 0x02 (y even) / 0x03 (y odd) || x big-endian; infinity = 33 zero bytes (SEC1's
 //                  one-byte 0x00, padded to the fixed width)
-// Decompression costs one square root per point: both base fields have p = 3 mod 4, so y = (x^3 + b)^((p+1)/4),
-// ~1.2 BITS Montgomery products, checked by squaring.  edwards25519 is not offered (not a reference backend).
+//   edwards25519 : 32 bytes, ristretto255 (RFC 9496; ristretto.hpp) -- the encoding IS the prime-order group: every
+//                  accepted string is an element, the 4-torsion is quotiented away
+// Decompression costs one square root per point: both Weierstrass base fields have p = 3 mod 4, so
+// y = (x^3 + b)^((p+1)/4), ~1.2 BITS Montgomery products, checked by squaring.
+// check_subgroup (decompression): also reject curve points outside the prime-order subgroup -- BLS12-381 G1 has
+// cofactor 0x396c8c00..aaab, so "on the curve" is not "in the group" (ec.hpp aff_in_prime_subgroup); a no-op for
+// secp256k1 (cofactor 1) and ristretto255.
 #pragma once
 #include "host_util.hpp"
 
@@ -19,12 +24,12 @@ namespace bpp {
 
 template <class C>
 struct has_codec {
-    static constexpr bool value = C::Fp::SQRT_3MOD4;
+    static constexpr bool value = true;
 };
 
 template <class C>
 constexpr int compressed_bytes() {
-    return C::ID == 0 ? 48 : 33;
+    return C::ID == 0 ? 48 : (C::ID == 1 ? 33 : 32);
 }
 
 // a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4 (MSB-first square-and-multiply over the
@@ -63,7 +68,14 @@ __global__ void __launch_bounds__(128) k_points_compress(const uint32_t* __restr
     const uint32_t* w = wire + i * (2 * N + 2);
     uint8_t* o = out + i * CB;
     const bool inf = (w[2 * N] | w[2 * N + 1]) != 0;
-    if (C::ID == 0) {
+    if constexpr (C::ID == 2) {
+        Aff<C> a = aff_inf<C>();
+        if (!inf) {
+            a.x = fe_from_canonical<P>(w);
+            a.y = fe_from_canonical<P>(w + N);
+        }
+        rist_encode(jac_from_aff(a), o);
+    } else if (C::ID == 0) {
         // x big-endian over 48 bytes; flags in the three top bits (x < p < 2^381 leaves them free)
         for (int b = 0; b < 48; b++) {
             const int k = 47 - b;   // byte k of the little-endian value
@@ -86,10 +98,11 @@ __global__ void __launch_bounds__(128) k_points_compress(const uint32_t* __restr
     }
 }
 
-// one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (bad flags, x >= p, x not on the curve)
+// one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (bad flags, x >= p, x not on the curve,
+// not a ristretto255 encoding; with check_subgroup also: outside the prime-order subgroup)
 template <class C>
 __global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
-                                                          uint32_t* __restrict__ ok, size_t n) {
+                                                          uint32_t* __restrict__ ok, size_t n, uint32_t check_subgroup) {
     using P = typename C::Fp;
     using F = Fe<P>;
     constexpr int N = P::N;
@@ -103,6 +116,15 @@ __global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restr
         w[2 * N] = 1;   // infinity, so that a consumer that ignores ok[] still sees a valid wire point
         ok[i] = 1;
     };
+    if constexpr (C::ID == 2) {
+        Aff<C> a;
+        if (!rist_decode(s, a)) return fail_point();
+        fe_to_canonical(a.x, w);
+        fe_to_canonical(a.y, w + N);
+        w[2 * N] = 0;
+        w[2 * N + 1] = 0;
+        ok[i] = 0;
+    } else {
     uint32_t x[N];
     for (int t = 0; t < N; t++) x[t] = 0;
     bool inf = false, want_flag = false;
@@ -157,6 +179,12 @@ __global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restr
         y = fe_neg(y);
         fe_to_canonical(y, yw);
     }
+    if (check_subgroup) {
+        Aff<C> a;
+        a.x = xm;
+        a.y = y;
+        if (!aff_in_prime_subgroup(a)) return fail_point();
+    }
     // y = 0 cannot carry the "larger" / "odd" flag; it does not occur on these curves (no point of order 2)
     for (int t = 0; t < N; t++) {
         w[t] = x[t];
@@ -165,6 +193,7 @@ __global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restr
     w[2 * N] = 0;
     w[2 * N + 1] = 0;
     ok[i] = 0;
+    }   // Weierstrass encodings
 }
 
 template <class C>
@@ -172,56 +201,74 @@ struct CodecImpl {
     static constexpr int N = C::Fp::N;
     static constexpr int WW = 2 * N + 2;
 
-    BPP_NOINL static int compress(const uint64_t* points, size_t n, uint8_t* out) {
-        if constexpr (!has_codec<C>::value) {
-            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
-        } else {
-            if (n == 0) return BPP_OK;
-            constexpr int CB = compressed_bytes<C>();
-            DevBuf dw, db;
-            HIPCHK(dw.alloc(n * WW * 4));
-            HIPCHK(db.alloc(n * CB));
-            HIPCHK(hipMemcpy(dw.p, points, n * WW * 4, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_points_compress<C>, dim3(cdiv(n, 128)), dim3(128), 0, nullptr, dw.u32(),
-                               static_cast<uint8_t*>(db.p), n);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpy(out, db.p, n * CB, hipMemcpyDeviceToHost));
-            return BPP_OK;
-        }
-    }
+    static int compress(const uint64_t* points, size_t n, uint8_t* out);
 
     // device to device: `d_in` n x CB bytes, `d_wire` n wire points, `d_ok` n words
-    BPP_NOINL static int decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st) {
-        if constexpr (!has_codec<C>::value) {
-            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
-        } else {
-            if (n == 0) return BPP_OK;
-            hipLaunchKernelGGL(k_points_decompress<C>, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in,
-                               reinterpret_cast<uint32_t*>(d_wire), d_ok, n);
-            HIPCHK(hipGetLastError());
-            return BPP_OK;
-        }
-    }
+    static int decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st,
+                                 bool check_subgroup = false);
 
-    BPP_NOINL static int decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
-        if constexpr (!has_codec<C>::value) {
-            return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
-        } else {
-            if (n == 0) return BPP_OK;
-            constexpr int CB = compressed_bytes<C>();
-            DevBuf dw, db, dk;
-            HIPCHK(dw.alloc(n * WW * 4));
-            HIPCHK(db.alloc(n * CB));
-            HIPCHK(dk.alloc(n * 4));
-            HIPCHK(hipMemcpy(db.p, in, n * CB, hipMemcpyHostToDevice));
-            int rc = decompress_device(static_cast<const uint8_t*>(db.p), n, static_cast<uint64_t*>(dw.p), dk.u32(), nullptr);
-            if (rc) return rc;
-            HIPCHK(hipMemcpy(out_points, dw.p, n * WW * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(out_ok, dk.p, n * 4, hipMemcpyDeviceToHost));
-            return BPP_OK;
-        }
-    }
+    static int decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok);
 };
+
+// ---- definitions: compiled only by the translation unit that instantiates the struct (tu_*.hip defines
+// BPP_IMPL_DEFINITIONS); capi.hip sees the declarations above and the `extern template` below, so it does not
+// compile the kernels a second time ----
+#ifdef BPP_IMPL_DEFINITIONS
+template <class C>
+int CodecImpl<C>::compress(const uint64_t* points, size_t n, uint8_t* out) {
+    if constexpr (!has_codec<C>::value) {
+        return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+    } else {
+        if (n == 0) return BPP_OK;
+        constexpr int CB = compressed_bytes<C>();
+        DevBuf dw, db;
+        HIPCHK(dw.alloc(n * WW * 4));
+        HIPCHK(db.alloc(n * CB));
+        HIPCHK(hipMemcpy(dw.p, points, n * WW * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_points_compress<C>, dim3(cdiv(n, 128)), dim3(128), 0, nullptr, dw.u32(),
+                           static_cast<uint8_t*>(db.p), n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(out, db.p, n * CB, hipMemcpyDeviceToHost));
+        return BPP_OK;
+    }
+}
+
+template <class C>
+int CodecImpl<C>::decompress_device(const uint8_t* d_in, size_t n, uint64_t* d_wire, uint32_t* d_ok, hipStream_t st,
+                                    bool check_subgroup) {
+    if constexpr (!has_codec<C>::value) {
+        return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+    } else {
+        if (n == 0) return BPP_OK;
+        hipLaunchKernelGGL(k_points_decompress<C>, dim3(cdiv(n, 64)), dim3(64), 0, st, d_in,
+                           reinterpret_cast<uint32_t*>(d_wire), d_ok, n, check_subgroup ? 1u : 0u);
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+}
+
+template <class C>
+int CodecImpl<C>::decompress(const uint8_t* in, size_t n, uint64_t* out_points, uint32_t* out_ok) {
+    if constexpr (!has_codec<C>::value) {
+        return fail(BPP_E_ARG, "compressed encoding is not offered for this curve");
+    } else {
+        if (n == 0) return BPP_OK;
+        constexpr int CB = compressed_bytes<C>();
+        DevBuf dw, db, dk;
+        HIPCHK(dw.alloc(n * WW * 4));
+        HIPCHK(db.alloc(n * CB));
+        HIPCHK(dk.alloc(n * 4));
+        HIPCHK(hipMemcpy(db.p, in, n * CB, hipMemcpyHostToDevice));
+        int rc = decompress_device(static_cast<const uint8_t*>(db.p), n, static_cast<uint64_t*>(dw.p), dk.u32(), nullptr);
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(out_points, dw.p, n * WW * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_ok, dk.p, n * 4, hipMemcpyDeviceToHost));
+        return BPP_OK;
+    }
+}
+
+#endif  // BPP_IMPL_DEFINITIONS
+
 
 extern template struct CodecImpl<Bls12381>;
 extern template struct CodecImpl<Secp256k1>;

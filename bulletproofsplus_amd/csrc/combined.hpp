@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_comb_verdict(const uint32_t* __restrict
     anybad = __syncthreads_or(anybad);
     if (threadIdx.x == 0) {
         Jac<C> acc = jac_ldg<C>(partial + threadIdx.x);
-        ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
+        ok[0] = (jac_is_identity_class(acc) && !anybad) ? 0u : 1u;
         uint32_t* flag = const_cast<uint32_t*>(partial) + jac_words<C>();   // travels with the partial to the other ranks
         flag[0] = anybad ? 1u : 0u;
         flag[1] = flag[2] = flag[3] = 0u;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __rest
         acc = jac_add(acc, jac_ldg<C>(partials + (size_t)t * stride));
         if (with_flags) anybad |= partials[(size_t)t * stride + JW];
     }
-    ok[0] = (acc.is_inf() && !anybad) ? 0u : 1u;
+    ok[0] = (jac_is_identity_class(acc) && !anybad) ? 0u : 1u;
     if (out) jac_stg<C>(out, acc);
 }
 

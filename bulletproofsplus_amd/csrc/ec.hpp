@@ -368,6 +368,51 @@ BPP_HD Jac<C> xyzz_to_jac(const Xyzz<C>& p) {
     return r;
 }
 
+// The verdict test of the verification MulVec: is the sum the identity of the group the PROOF lives in?  For the
+// Weierstrass curves that is the point at infinity; the Edwards instantiation overrides it with the identity of
+// ristretto255's quotient group (ristretto.hpp).
+template <class C>
+BPP_HD bool jac_is_identity_class(const Jac<C>& p) {
+    return p.is_inf();
+}
+
+// Membership of the prime-order subgroup for points that arrive SERIALIZED (container.hpp / codec.hpp; the in-memory
+// API takes points that are valid by construction, as the reference's mcl / BigUint values are).
+//   BLS12-381 G1 (cofactor 0x396c8c005555e1568c00aaab0000aaab): the endomorphism phi(x, y) = (beta x, y) acts on G1 as
+//   multiplication by -z^2 (z = -0xd201000000010000, r = z^4 - z^2 + 1), and a curve point lies in G1 iff
+//   phi(P) = -[z^2] P (Scott, "A note on group membership tests for G1, G2 and GT on BLS pairing-friendly curves",
+//   eprint 2021/1130): two multiplications by the sparse 64-bit |z| instead of one by the 255-bit r.  Checked against
+//   [r] P == O on random, torsion and mixed points by tests/test_container_cpu.py.
+//   secp256k1 has cofactor 1: every curve point is in the group.
+template <class C>
+BPP_HD bool aff_in_prime_subgroup(const Aff<C>& p) {
+    if constexpr (C::ID == 0) {
+        using F = Fe<typename C::Fp>;
+        if (p.is_inf()) return true;
+        Jac<C> t = jac_from_aff(p);
+        for (int pass = 0; pass < 2; pass++) {   // t <- [|z|] t, twice
+            const Jac<C> base = t;
+            Jac<C> acc = jac_inf<C>();
+            for (int i = 63; i >= 0; i--) {
+                acc = jac_dbl(acc);
+                if ((C::K::ZABS >> i) & 1ull) acc = jac_add(acc, base);
+            }
+            t = acc;
+        }
+        // phi(P) + [z^2] P == O  <=>  [z^2] P == (beta x, -y)
+        if (t.is_inf()) return false;
+        F beta;
+#pragma unroll
+        for (int i = 0; i < C::Fp::NL; i++) beta.l[i] = C::K::BETA[i];
+        const F zz = fe_sqr(t.Z);
+        if (fe_mul(fe_mul(beta, p.x), zz) != t.X) return false;
+        return fe_mul(fe_neg(p.y), fe_mul(zz, t.Z)) == t.Y;
+    } else {
+        (void)p;
+        return true;
+    }
+}
+
 // Same group element?  (cross-multiplied comparison, no inversion)
 template <class C>
 BPP_HD bool jac_eq(const Jac<C>& p, const Jac<C>& q) {

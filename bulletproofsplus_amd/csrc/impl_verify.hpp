@@ -100,151 +100,15 @@ struct VerifyImpl {
         return w;
     }
 
-    BPP_NOINL static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
-                      int window_bits, bpp_verifier** out) {
-        VerifyShape s;
-        int rc = make_shape(n, m, window_bits, C::Fr::MODW, C::Fr::BITS, s);
-        if (rc) return rc;
-        std::vector<uint64_t> fixed((size_t)s.NF * PW);
-        std::memcpy(fixed.data(), gh, 2 * PW * 8);
-        std::memcpy(fixed.data() + 2 * PW, G, (size_t)s.mn * PW * 8);
-        std::memcpy(fixed.data() + (size_t)(2 + s.mn) * PW, H, (size_t)s.mn * PW * 8);
-        DevBuf dfixed;
-        rc = upload_points<C>(fixed.data(), s.NF, dfixed, nullptr);
-        if (rc) return rc;
-        if (vs_lds_bytes<C>(s) > 64 * 1024) {
-            // above the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_verify_scalars<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
-        }
-        bpp_verifier* v = new bpp_verifier();
-        v->ctx = ctx;
-        v->s = s;
-        const size_t entries = (size_t)s.NF * s.per_f;
-        v->table_bytes = entries * 2 * N * 4;
-        hipError_t e = v->table.alloc(v->table_bytes);
-        if (e != hipSuccess) {
-            delete v;
-            return fail(BPP_E_NOMEM, std::string("window table allocation failed: ") + hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL(k_tbl_bases<C>, dim3(cdiv(s.NF, 64)), dim3(64), 0, nullptr, s, dfixed.u32(), v->table.u32());
-        // fill in slabs of generators: one thread per run of TBL_RUN entries, 2 * TBL_RUN field elements of scratch each
-        const uint32_t runs_f = tbl_runs_per_generator(s);
-        const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 21) / runs_f);
-        DevBuf tbl_scratch;
-        e = tbl_scratch.alloc((size_t)std::min<uint32_t>(slab, s.NF) * runs_f * 2 * TBL_RUN * N * 4);
-        if (e != hipSuccess) {
-            delete v;
-            return fail(BPP_E_NOMEM, std::string("table scratch allocation failed: ") + hipGetErrorString(e));
-        }
-        for (uint32_t f0 = 0; f0 < s.NF; f0 += slab) {
-            const uint32_t f1 = std::min<uint32_t>(s.NF, f0 + slab);
-            const size_t total = (size_t)(f1 - f0) * runs_f;
-            hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, s, v->table.u32(),
-                               tbl_scratch.u32(), f0, f1);
-        }
-        tr_initial_state(C::ID, s.n, s.m, reinterpret_cast<const uint32_t*>(fixed.data()), fixed.size() * 2, v->tr0.st);
-        std::vector<uint32_t> ch;
-        default_challenges(s, ch);
-        e = v->challenges.alloc(ch.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(v->challenges.p, ch.data(), ch.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) {
-            delete v;
-            return fail(BPP_E_HIP, std::string("table build failed: ") + hipGetErrorString(e));
-        }
-        *out = v;
-        return BPP_OK;
-    }
+    static int create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
+                      int window_bits, bpp_verifier** out);
 
-    BPP_NOINL static int run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+    static int run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
                    const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
-                   uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st) {
-        const VerifyShape& s = v->s;
-        const WsLayout L = ws_layout(s, count);
-        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
-        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
-        uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
-        uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
-        uint32_t* w_sc = d_out_scalars ? reinterpret_cast<uint32_t*>(d_out_scalars)
-                                       : reinterpret_cast<uint32_t*>(ws + L.scalars);
-        uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
-        uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
-        uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
-        const unsigned bpp_ = blocks_per_proof(s, count);
-        const size_t npts = count * s.NV;
-        hipEvent_t* ev = nullptr;   // ev[2 * stage], ev[2 * stage + 1]
-        if (v->profiling) {
-            ev = v->events.data() + (v->passes_recorded % BPP_PROFILE_SLOTS) * (BPP_NUM_STAGES * 2);
-            v->passes_recorded++;
-        }
-        auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
-        v->last_blocks_per_proof = bpp_;
-        HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
-        HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
-        hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
-                           reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
-        HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
-        const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
-        const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
-        HIPCHK(mark(2 * BPP_STAGE_SCALARS, st));
-        hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
-                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
-        HIPCHK(mark(2 * BPP_STAGE_SCALARS + 1, st));
-        // proof-point MSM: digits, per-point tables, window sums (all arithmetic bound, so they simply run in
-        // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
-        uint8_t* w_vd = ws + L.vdig;
-        uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
-        const size_t vlanes = count * VAR_WINDOWS;
-        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
-        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
-        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
-                           reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
-        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                           vlanes);
-        HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
-        HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-        // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree)
-        const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
-        const unsigned hb = tree ? cdiv(count, FIXED_BLOCK / 64) : cdiv(count, FIXED_BLOCK);
-        uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
-        hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                           w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u});
-        HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
-        HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
-        // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
-        // k_finalize adds the rest
-        const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);
-        const unsigned folded2 = folded / FOLD_GROUP2;
-        uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
-        hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
-                           count * folded);
-        hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
-                           count * folded2);
-        const uint32_t* w_last = w_fp2;
-        unsigned last = folded2;
-        if (bpp_ > 1) {   // several blocks per proof: one more pass, so that k_finalize always sees 4 partials
-            uint32_t* w_fp3 = reinterpret_cast<uint32_t*>(ws + L.fpart3);
-            last = folded2 / bpp_;
-            hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * last, 64)), dim3(64), 0, st, w_fp2, bpp_, w_fp3,
-                               count * last);
-            w_last = w_fp3;
-        }
-        hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_last, last, w_vp, 1u, w_bad, d_ok,
-                           reinterpret_cast<uint32_t*>(d_out_result), count);
-        HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
-        HIPCHK(hipGetLastError());
-        return BPP_OK;
-    }
+                   uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st);
 
-    BPP_NOINL static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
-                                 hipStream_t st) {
-        hipLaunchKernelGGL(k_transcript_challenges<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, v->s, v->tr0,
-                           reinterpret_cast<const uint32_t*>(d_points), reinterpret_cast<uint32_t*>(d_challenges), count);
-        HIPCHK(hipGetLastError());
-        return BPP_OK;
-    }
+    static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
+                                 hipStream_t st);
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
@@ -287,71 +151,10 @@ struct VerifyImpl {
     }
 
     // d_out_partial: one jacobian (3N words, opaque to the caller) = this batch's weighted sum
-    BPP_NOINL static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+    static int run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
                             const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
                             const uint64_t* d_weights, uint32_t* d_out_partial, uint32_t* d_ok, void* d_workspace,
-                            size_t workspace_bytes, hipStream_t st) {
-        const VerifyShape& s = v->s;
-        const CombLayout L = comb_layout(s, count);
-        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
-        if (count * s.NV >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "count too large");
-        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
-        uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
-        uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
-        uint32_t* w_sc = reinterpret_cast<uint32_t*>(ws + L.scalars);
-        uint32_t* w_wt = reinterpret_cast<uint32_t*>(ws + L.weights);
-        uint32_t* w_cs = reinterpret_cast<uint32_t*>(ws + L.comb_sc);
-        uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
-        uint32_t* w_vs = reinterpret_cast<uint32_t*>(ws + L.var_sc);
-        uint8_t* w_vd = ws + L.vdig;
-        uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
-        uint32_t* w_vscr = reinterpret_cast<uint32_t*>(ws + L.vscr);
-        uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
-        uint32_t* w_vf = reinterpret_cast<uint32_t*>(ws + L.vfold);
-        const size_t items = count * s.NV;
-        HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
-        HIPCHK(hipMemsetAsync(w_cs, 0, (size_t)s.N * 32, st));
-        hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
-                           reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
-        const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
-        const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
-        hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
-                           reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
-        WeightKey wk;
-        for (int i = 0; i < 8; i++)
-            wk.w[i] = d_weights ? 0u
-                                : (uint32_t)weight_key[4 * i] | ((uint32_t)weight_key[4 * i + 1] << 8) |
-                                      ((uint32_t)weight_key[4 * i + 2] << 16) | ((uint32_t)weight_key[4 * i + 3] << 24);
-        hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, wk, index_base,
-                           reinterpret_cast<const uint32_t*>(d_weights), w_wt, count);
-        hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
-        // proof-carried points: weighted scalars -> per-proof Straus window sums -> summed across proofs per window
-        hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
-        hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
-        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
-        const size_t vlanes = count * VAR_WINDOWS;
-        hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                           vlanes);
-        uint32_t* cur = w_vw;
-        uint32_t* nxt = w_vf;
-        for (size_t nrem = count; nrem > 1;) {
-            const size_t groups = cdiv(nrem, COMB_FOLD_GROUP);
-            hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * VAR_WINDOWS, 64)), dim3(64), 0, st, cur, nrem,
-                               COMB_FOLD_GROUP, nxt, groups * VAR_WINDOWS);
-            std::swap(cur, nxt);
-            nrem = groups;
-        }
-        // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
-        // leading block; the Horner result lands behind the block sums
-        hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
-                           v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u,
-                           VpSel{1u, 0u, 1u});
-        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
-                           d_out_partial);
-        hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
-        HIPCHK(hipGetLastError());
-        return BPP_OK;
-    }
+                            size_t workspace_bytes, hipStream_t st);
 
     // ---- batched prover (prover_batch.hpp) -------------------------------------------------------------
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
@@ -406,117 +209,352 @@ struct VerifyImpl {
     // fs = true : challenges from the transcript (transcript.hpp): A and the commitments first, then y, z; each round's
     //             L_t, R_t before e_t; wip.A, wip.B before e -- 3 + k smaller launches and the hashing steps between
     //             them.  d_out_challenges (count x (3 + k) scalars, may be null) receives [y, z, e, e_1..e_k].
-    BPP_NOINL static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
+    static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
                                   uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
-                                  uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st) {
-        const VerifyShape& s = v->s;
-        const uint32_t k = s.k, m = s.m;
-        const uint32_t nvp = pb_num_vps(k, m);
-        const ProveLayout L = prove_layout(s, count);
-        if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
-        ProverConsts pc;
-        pc.alpha = m == 1 ? 7 : 33;   // range/mod.rs:94 / :256
-        pc.d_L = 4;                   // wip.rs:94
-        pc.d_R = 5;                   // wip.rs:95
-        pc.r = 33;                    // wip.rs:175
-        pc.s = 44;
-        pc.delta = 88;
-        pc.eta = 123;
-        uint8_t* ws = static_cast<uint8_t*>(d_workspace);
-        auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
-        for (size_t base = 0; base < count; base += L.chunk) {
-            const size_t cnt = std::min(L.chunk, count - base);
-            uint32_t* o_pts = reinterpret_cast<uint32_t*>(d_out_points) + base * (size_t)(3 + 2 * k) * WW;
-            uint32_t* o_sc = reinterpret_cast<uint32_t*>(d_out_scalars) + base * 24;
-            uint32_t* o_V = d_out_V ? reinterpret_cast<uint32_t*>(d_out_V) + base * (size_t)m * WW : W(L.vout);
-            const uint64_t* vals = d_values + base * m;
-            const uint32_t* gams = reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8;
-            // one MulVec launch over `sel` of every proof's virtual proofs, then their wire points into the records
-            auto msm = [&](VpSel sel) {
-                const size_t nv = cnt * sel.cnt;
-                // never more blocks per virtual proof than the workspace was sized for
-                const unsigned per = std::min(L.per, blocks_per_proof(s, nv));
-                hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                                   W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
-                                   (uint32_t*)nullptr, (size_t)0, 0u, sel);
-                hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv, 64)), dim3(64), 0, st, s, sel, W(L.part), per, o_pts, o_V, nv);
-            };
-            if (!fs) {
-                hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, 0u, vals, gams,
-                                   v->challenges.u32(), 0u, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-                for (uint32_t t = 0; t < k; t++)
-                    hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_ALL, W(L.a),
-                                       W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-                hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, W(L.a), W(L.b),
-                                   W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
-                msm(VpSel{nvp, 0u, nvp});
-                continue;
-            }
-            uint32_t* o_ch = d_out_challenges ? reinterpret_cast<uint32_t*>(d_out_challenges) + base * (size_t)(3 + k) * 8
-                                              : W(L.ch);
-            const uint32_t chs = (3 + k) * 8;
-            const unsigned lanes = cdiv(cnt, 64);
-            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
-                               chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            msm(VpSel{nvp, 0u, 1u});               // A
-            msm(VpSel{nvp, 2 * k + 3, m});         // V_0 .. V_{m-1}
-            hipLaunchKernelGGL(k_pb_fs_yz<C>, dim3(lanes), dim3(64), 0, st, s, v->tr0, o_pts, o_V, W(L.trst), o_ch, cnt);
-            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
-                               chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            for (uint32_t t = 0; t < k; t++) {
-                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
-                                   W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-                msm(VpSel{nvp, 1 + 2 * t, 2u});    // L_t, R_t
-                hipLaunchKernelGGL(k_pb_fs_round<C>, dim3(lanes), dim3(64), 0, st, s, t, o_pts, W(L.trst), o_ch, W(L.con), cnt);
-                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_POST, W(L.a),
-                                   W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            }
-            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, W(L.a), W(L.b),
-                               W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
-            msm(VpSel{nvp, 2 * k + 1, 2u});        // wip.A, wip.B
-            hipLaunchKernelGGL(k_pb_fs_final<C>, dim3(lanes), dim3(64), 0, st, s, o_pts, W(L.trst), o_ch, W(L.con), cnt);
-            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, W(L.a), W(L.b),
-                               W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
-        }
-        HIPCHK(hipGetLastError());
-        return BPP_OK;
-    }
+                                  uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st);
 
     // host buffers in, host buffers out
-    BPP_NOINL static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
-                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs) {
-        const VerifyShape& s = v->s;
-        const uint32_t k = s.k, m = s.m;
-        hipStream_t st = nullptr;
-        const ProveLayout L = prove_layout(s, count);
-        DevBuf d_val, d_gam, d_pts, d_V, d_sc, d_ws;
-        HIPCHK(d_val.alloc(count * m * 8));
-        HIPCHK(hipMemcpyAsync(d_val.p, values, count * m * 8, hipMemcpyHostToDevice, st));
-        int rc = upload_scalars<C>(gammas, count * m, d_gam, st);
-        if (rc) return rc;
-        HIPCHK(d_pts.alloc(count * (size_t)(3 + 2 * k) * WW * 4));
-        HIPCHK(d_V.alloc(count * (size_t)m * WW * 4));
-        HIPCHK(d_sc.alloc(count * 3 * 32));
-        HIPCHK(d_ws.alloc(L.total));
-        rc = prove_batch_device(v, static_cast<const uint64_t*>(d_val.p), static_cast<const uint64_t*>(d_gam.p), count,
-                                static_cast<uint64_t*>(d_pts.p), static_cast<uint64_t*>(d_sc.p),
-                                static_cast<uint64_t*>(d_V.p), fs, nullptr, d_ws.p, L.total, st);
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(out_points, d_pts.p, count * (size_t)(3 + 2 * k) * WW * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(out_scalars, d_sc.p, count * 96, hipMemcpyDeviceToHost, st));
-        if (out_V) HIPCHK(hipMemcpyAsync(out_V, d_V.p, count * (size_t)m * WW * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        return BPP_OK;
-    }
+    static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
+                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs);
 
     // d_partials: n partials as bpp_verifier_run_combined wrote them (jacobian + validity word each)
-    BPP_NOINL static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
-        hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n,
-                           (uint32_t)partial_words<C>(), 1u, d_ok, (uint32_t*)nullptr);
-        HIPCHK(hipGetLastError());
-        return BPP_OK;
-    }
+    static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st);
 };
+
+// ---- definitions: compiled only by the translation unit that instantiates the struct (tu_*.hip defines
+// BPP_IMPL_DEFINITIONS); capi.hip sees the declarations above and the `extern template` below, so it does not
+// compile the kernels a second time ----
+#ifdef BPP_IMPL_DEFINITIONS
+template <class C>
+int VerifyImpl<C>::create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
+                  int window_bits, bpp_verifier** out) {
+    VerifyShape s;
+    int rc = make_shape(n, m, window_bits, C::Fr::MODW, C::Fr::BITS, s);
+    if (rc) return rc;
+    std::vector<uint64_t> fixed((size_t)s.NF * PW);
+    std::memcpy(fixed.data(), gh, 2 * PW * 8);
+    std::memcpy(fixed.data() + 2 * PW, G, (size_t)s.mn * PW * 8);
+    std::memcpy(fixed.data() + (size_t)(2 + s.mn) * PW, H, (size_t)s.mn * PW * 8);
+    DevBuf dfixed;
+    rc = upload_points<C>(fixed.data(), s.NF, dfixed, nullptr);
+    if (rc) return rc;
+    if (vs_lds_bytes<C>(s) > 64 * 1024) {
+        // above the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_verify_scalars<C>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
+    }
+    bpp_verifier* v = new bpp_verifier();
+    v->ctx = ctx;
+    v->s = s;
+    const size_t entries = (size_t)s.NF * s.per_f;
+    v->table_bytes = entries * 2 * N * 4;
+    hipError_t e = v->table.alloc(v->table_bytes);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(BPP_E_NOMEM, std::string("window table allocation failed: ") + hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_tbl_bases<C>, dim3(cdiv(s.NF, 64)), dim3(64), 0, nullptr, s, dfixed.u32(), v->table.u32());
+    // fill in slabs of generators: one thread per run of TBL_RUN entries, 2 * TBL_RUN field elements of scratch each
+    const uint32_t runs_f = tbl_runs_per_generator(s);
+    const uint32_t slab = (uint32_t)std::max<size_t>(1, ((size_t)1 << 21) / runs_f);
+    DevBuf tbl_scratch;
+    e = tbl_scratch.alloc((size_t)std::min<uint32_t>(slab, s.NF) * runs_f * 2 * TBL_RUN * N * 4);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(BPP_E_NOMEM, std::string("table scratch allocation failed: ") + hipGetErrorString(e));
+    }
+    for (uint32_t f0 = 0; f0 < s.NF; f0 += slab) {
+        const uint32_t f1 = std::min<uint32_t>(s.NF, f0 + slab);
+        const size_t total = (size_t)(f1 - f0) * runs_f;
+        hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, s, v->table.u32(),
+                           tbl_scratch.u32(), f0, f1);
+    }
+    tr_initial_state(C::ID, s.n, s.m, reinterpret_cast<const uint32_t*>(fixed.data()), fixed.size() * 2, v->tr0.st);
+    std::vector<uint32_t> ch;
+    default_challenges(s, ch);
+    e = v->challenges.alloc(ch.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(v->challenges.p, ch.data(), ch.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        delete v;
+        return fail(BPP_E_HIP, std::string("table build failed: ") + hipGetErrorString(e));
+    }
+    *out = v;
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+               const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
+               uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st) {
+    const VerifyShape& s = v->s;
+    const WsLayout L = ws_layout(s, count);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
+    uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
+    uint32_t* w_sc = d_out_scalars ? reinterpret_cast<uint32_t*>(d_out_scalars)
+                                   : reinterpret_cast<uint32_t*>(ws + L.scalars);
+    uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
+    uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
+    uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
+    const unsigned bpp_ = blocks_per_proof(s, count);
+    const size_t npts = count * s.NV;
+    hipEvent_t* ev = nullptr;   // ev[2 * stage], ev[2 * stage + 1]
+    if (v->profiling) {
+        ev = v->events.data() + (v->passes_recorded % BPP_PROFILE_SLOTS) * (BPP_NUM_STAGES * 2);
+        v->passes_recorded++;
+    }
+    auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
+    v->last_blocks_per_proof = bpp_;
+    HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+    HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
+    hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
+                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
+    HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
+    const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
+    const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+    HIPCHK(mark(2 * BPP_STAGE_SCALARS, st));
+    hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
+                       reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
+    HIPCHK(mark(2 * BPP_STAGE_SCALARS + 1, st));
+    // proof-point MSM: digits, per-point tables, window sums (all arithmetic bound, so they simply run in
+    // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
+    uint8_t* w_vd = ws + L.vdig;
+    uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
+    const size_t vlanes = count * VAR_WINDOWS;
+    HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
+    hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
+    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
+                       reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
+    hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
+                       vlanes);
+    HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
+    HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
+    // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree)
+    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
+    const unsigned hb = tree ? cdiv(count, FIXED_BLOCK / 64) : cdiv(count, FIXED_BLOCK);
+    uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
+    hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
+                       w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u});
+    HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
+    HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
+    // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
+    // k_finalize adds the rest
+    const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);
+    const unsigned folded2 = folded / FOLD_GROUP2;
+    uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
+    hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
+                       count * folded);
+    hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
+                       count * folded2);
+    const uint32_t* w_last = w_fp2;
+    unsigned last = folded2;
+    if (bpp_ > 1) {   // several blocks per proof: one more pass, so that k_finalize always sees 4 partials
+        uint32_t* w_fp3 = reinterpret_cast<uint32_t*>(ws + L.fpart3);
+        last = folded2 / bpp_;
+        hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * last, 64)), dim3(64), 0, st, w_fp2, bpp_, w_fp3,
+                           count * last);
+        w_last = w_fp3;
+    }
+    hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_last, last, w_vp, 1u, w_bad, d_ok,
+                       reinterpret_cast<uint32_t*>(d_out_result), count);
+    HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(k_transcript_challenges<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, v->s, v->tr0,
+                       reinterpret_cast<const uint32_t*>(d_points), reinterpret_cast<uint32_t*>(d_challenges), count);
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                        const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                        const uint64_t* d_weights, uint32_t* d_out_partial, uint32_t* d_ok, void* d_workspace,
+                        size_t workspace_bytes, hipStream_t st) {
+    const VerifyShape& s = v->s;
+    const CombLayout L = comb_layout(s, count);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    if (count * s.NV >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "count too large");
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    uint32_t* w_pts = reinterpret_cast<uint32_t*>(ws + L.pts);
+    uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
+    uint32_t* w_sc = reinterpret_cast<uint32_t*>(ws + L.scalars);
+    uint32_t* w_wt = reinterpret_cast<uint32_t*>(ws + L.weights);
+    uint32_t* w_cs = reinterpret_cast<uint32_t*>(ws + L.comb_sc);
+    uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
+    uint32_t* w_vs = reinterpret_cast<uint32_t*>(ws + L.var_sc);
+    uint8_t* w_vd = ws + L.vdig;
+    uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
+    uint32_t* w_vscr = reinterpret_cast<uint32_t*>(ws + L.vscr);
+    uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
+    uint32_t* w_vf = reinterpret_cast<uint32_t*>(ws + L.vfold);
+    const size_t items = count * s.NV;
+    HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+    HIPCHK(hipMemsetAsync(w_cs, 0, (size_t)s.N * 32, st));
+    hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
+                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
+    const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
+    const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+    hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
+                       reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
+    WeightKey wk;
+    for (int i = 0; i < 8; i++)
+        wk.w[i] = d_weights ? 0u
+                            : (uint32_t)weight_key[4 * i] | ((uint32_t)weight_key[4 * i + 1] << 8) |
+                                  ((uint32_t)weight_key[4 * i + 2] << 16) | ((uint32_t)weight_key[4 * i + 3] << 24);
+    hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, wk, index_base,
+                       reinterpret_cast<const uint32_t*>(d_weights), w_wt, count);
+    hipLaunchKernelGGL(k_comb_fixed<C>, dim3(s.NF), dim3(256), 0, st, s, w_sc, w_wt, count, w_cs);
+    // proof-carried points: weighted scalars -> per-proof Straus window sums -> summed across proofs per window
+    hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
+    hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
+    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
+    const size_t vlanes = count * VAR_WINDOWS;
+    hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
+                       vlanes);
+    uint32_t* cur = w_vw;
+    uint32_t* nxt = w_vf;
+    for (size_t nrem = count; nrem > 1;) {
+        const size_t groups = cdiv(nrem, COMB_FOLD_GROUP);
+        hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * VAR_WINDOWS, 64)), dim3(64), 0, st, cur, nrem,
+                           COMB_FOLD_GROUP, nxt, groups * VAR_WINDOWS);
+        std::swap(cur, nxt);
+        nrem = groups;
+    }
+    // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
+    // leading block; the Horner result lands behind the block sums
+    hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
+                       v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u,
+                       VpSel{1u, 0u, 1u});
+    hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
+                       d_out_partial);
+    hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
+                              uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
+                              uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+    const VerifyShape& s = v->s;
+    const uint32_t k = s.k, m = s.m;
+    const uint32_t nvp = pb_num_vps(k, m);
+    const ProveLayout L = prove_layout(s, count);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    ProverConsts pc;
+    pc.alpha = m == 1 ? 7 : 33;   // range/mod.rs:94 / :256
+    pc.d_L = 4;                   // wip.rs:94
+    pc.d_R = 5;                   // wip.rs:95
+    pc.r = 33;                    // wip.rs:175
+    pc.s = 44;
+    pc.delta = 88;
+    pc.eta = 123;
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+    for (size_t base = 0; base < count; base += L.chunk) {
+        const size_t cnt = std::min(L.chunk, count - base);
+        uint32_t* o_pts = reinterpret_cast<uint32_t*>(d_out_points) + base * (size_t)(3 + 2 * k) * WW;
+        uint32_t* o_sc = reinterpret_cast<uint32_t*>(d_out_scalars) + base * 24;
+        uint32_t* o_V = d_out_V ? reinterpret_cast<uint32_t*>(d_out_V) + base * (size_t)m * WW : W(L.vout);
+        const uint64_t* vals = d_values + base * m;
+        const uint32_t* gams = reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8;
+        // one MulVec launch over `sel` of every proof's virtual proofs, then their wire points into the records
+        auto msm = [&](VpSel sel) {
+            const size_t nv = cnt * sel.cnt;
+            // never more blocks per virtual proof than the workspace was sized for
+            const unsigned per = std::min(L.per, blocks_per_proof(s, nv));
+            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
+                               W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
+                               (uint32_t*)nullptr, (size_t)0, 0u, sel);
+            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv, 64)), dim3(64), 0, st, s, sel, W(L.part), per, o_pts, o_V, nv);
+        };
+        if (!fs) {
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, 0u, vals, gams,
+                               v->challenges.u32(), 0u, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            for (uint32_t t = 0; t < k; t++)
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_ALL, W(L.a),
+                                   W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, W(L.a), W(L.b),
+                               W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
+            msm(VpSel{nvp, 0u, nvp});
+            continue;
+        }
+        uint32_t* o_ch = d_out_challenges ? reinterpret_cast<uint32_t*>(d_out_challenges) + base * (size_t)(3 + k) * 8
+                                          : W(L.ch);
+        const uint32_t chs = (3 + k) * 8;
+        const unsigned lanes = cdiv(cnt, 64);
+        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
+                           chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+        msm(VpSel{nvp, 0u, 1u});               // A
+        msm(VpSel{nvp, 2 * k + 3, m});         // V_0 .. V_{m-1}
+        hipLaunchKernelGGL(k_pb_fs_yz<C>, dim3(lanes), dim3(64), 0, st, s, v->tr0, o_pts, o_V, W(L.trst), o_ch, cnt);
+        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
+                           chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+        for (uint32_t t = 0; t < k; t++) {
+            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
+                               W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+            msm(VpSel{nvp, 1 + 2 * t, 2u});    // L_t, R_t
+            hipLaunchKernelGGL(k_pb_fs_round<C>, dim3(lanes), dim3(64), 0, st, s, t, o_pts, W(L.trst), o_ch, W(L.con), cnt);
+            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_POST, W(L.a),
+                               W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
+        }
+        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, W(L.a), W(L.b),
+                           W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
+        msm(VpSel{nvp, 2 * k + 1, 2u});        // wip.A, wip.B
+        hipLaunchKernelGGL(k_pb_fs_final<C>, dim3(lanes), dim3(64), 0, st, s, o_pts, W(L.trst), o_ch, W(L.con), cnt);
+        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, W(L.a), W(L.b),
+                           W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
+    }
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
+                       uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs) {
+    const VerifyShape& s = v->s;
+    const uint32_t k = s.k, m = s.m;
+    hipStream_t st = nullptr;
+    const ProveLayout L = prove_layout(s, count);
+    DevBuf d_val, d_gam, d_pts, d_V, d_sc, d_ws;
+    HIPCHK(d_val.alloc(count * m * 8));
+    HIPCHK(hipMemcpyAsync(d_val.p, values, count * m * 8, hipMemcpyHostToDevice, st));
+    int rc = upload_scalars<C>(gammas, count * m, d_gam, st);
+    if (rc) return rc;
+    HIPCHK(d_pts.alloc(count * (size_t)(3 + 2 * k) * WW * 4));
+    HIPCHK(d_V.alloc(count * (size_t)m * WW * 4));
+    HIPCHK(d_sc.alloc(count * 3 * 32));
+    HIPCHK(d_ws.alloc(L.total));
+    rc = prove_batch_device(v, static_cast<const uint64_t*>(d_val.p), static_cast<const uint64_t*>(d_gam.p), count,
+                            static_cast<uint64_t*>(d_pts.p), static_cast<uint64_t*>(d_sc.p),
+                            static_cast<uint64_t*>(d_V.p), fs, nullptr, d_ws.p, L.total, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_points, d_pts.p, count * (size_t)(3 + 2 * k) * WW * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out_scalars, d_sc.p, count * 96, hipMemcpyDeviceToHost, st));
+    if (out_V) HIPCHK(hipMemcpyAsync(out_V, d_V.p, count * (size_t)m * WW * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st) {
+    hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, d_partials, (uint32_t)n,
+                       (uint32_t)partial_words<C>(), 1u, d_ok, (uint32_t*)nullptr);
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+#endif  // BPP_IMPL_DEFINITIONS
+
 
 extern template struct VerifyImpl<Bls12381>;
 extern template struct VerifyImpl<Secp256k1>;

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include "ec.hpp"
 #include "ed25519.hpp"
+#include "ristretto.hpp"
 #include "transcript.hpp"
 
 namespace bpp {
@@ -1077,7 +1078,7 @@ __global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fi
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * JW));
     for (uint32_t t = 0; t < nv; t++) acc = jac_add(acc, jac_ldg<C>(var_partials + (b * nv + t) * JW));
-    ok[b] = (acc.is_inf() && !bad[b]) ? 0u : 1u;
+    ok[b] = (jac_is_identity_class(acc) && !bad[b]) ? 0u : 1u;
     if (wire_result) {
         uint32_t w[2 * N + 2];
         aff_to_wire(jac_to_aff(acc), w);

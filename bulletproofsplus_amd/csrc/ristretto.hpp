@@ -134,8 +134,10 @@ BPP_HD bool rist_equal(const Aff<Ed25519>& a, const Aff<Ed25519>& b) {
     return fe_mul(a.x, b.y) == fe_mul(a.y, b.x) || fe_mul(a.y, b.y) == fe_mul(a.x, b.x);
 }
 
-// the identity of the quotient group: a point of E[4], x = 0 or y = 0
+// the identity of the quotient group: a point of E[4], x = 0 or y = 0.  On prime-order inputs the only such point a
+// sum can reach is (0, 1), so this is also the exact test there.
 BPP_HD bool ed_is_identity_class(const Jac<Ed25519>& p) { return p.X.is_zero() || p.Y.is_zero(); }
+BPP_HD bool jac_is_identity_class(const Jac<Ed25519>& p) { return ed_is_identity_class(p); }
 
 // MAP of RFC 9496 4.3.4 (the Elligator-2 based one-way map) on a field element t
 BPP_HD Jac<Ed25519> rist_map(const Fe<EdFp>& t) {

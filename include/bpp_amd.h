@@ -43,6 +43,7 @@ extern "C" {
 
 #define BPP_OK 0
 #define BPP_VERIFICATION_ERROR 1
+#define BPP_FORMAT_ERROR 2  /* ProofError::FormatError (src/errors.rs:20): per-proof status of the serialized-proof path */
 #define BPP_E_ARG (-1)      /* bad argument (null pointer, unknown curve, n*m not a power of two...) */
 #define BPP_E_HIP (-2)      /* HIP runtime error; bpp_last_error() has the text */
 #define BPP_E_LENGTH (-3)   /* "mulvec: lengths of scalars and points must match" and friends */
@@ -227,7 +228,7 @@ int bpp_range_verify_batch(bpp_verifier *v, const uint64_t *points, const uint64
  * encodings' public generator vectors and oracle/pyref.py.
  *   BLS12-381 G1: 48 bytes, x big-endian, byte 0 bit 7 = compressed, bit 6 = infinity, bit 5 = y > (p-1)/2
  *   secp256k1   : 33 bytes, SEC1 02/03 || x big-endian; infinity = 33 zero bytes
- * (0 bytes = not offered: edwards25519.)  Decompression runs on the device (one square root per point);
+ *   edwards25519: 32 bytes, ristretto255 (RFC 9496): the encoding of the prime-order quotient group, csrc/ristretto.hpp  Decompression runs on the device (one square root per point);
  * out_ok[i] = 0 valid, 1 malformed (flags, x >= p, x not on the curve) -- such a point is returned as infinity. */
 size_t bpp_point_compressed_bytes(int curve_id);
 int bpp_points_compress(bpp_ctx *ctx, const uint64_t *points, size_t n, uint8_t *out);
@@ -240,6 +241,30 @@ int bpp_points_decompress_device(bpp_ctx *ctx, const void *d_in, size_t n, uint6
  * rejects its proof. */
 int bpp_range_verify_batch_compressed(bpp_verifier *v, const uint8_t *records, const uint64_t *scalars, size_t count,
                                       uint32_t *out_ok);
+
+/* ---- serialized proofs: the container -------------------------------------------------------------------
+ * The reference never serializes a proof; its commented-out size() functions (src/range/mod.rs:512-517,
+ * src/weighted_inner_product_proof.rs:384-397) count compressed points and 32-byte scalars, and src/errors.rs:20
+ * reserves ProofError::FormatError for a deserializer.  PARITY UNPINNED; pinned by oracle/pyref.py's restatement.
+ * One proof = bpp_proof_bytes(curve, n, m) bytes:
+ *   "BPP+" | version = 1 | curve id | n | m | k = log2(n m) | 0 0 0            (12 bytes)
+ *   A, wip.A, wip.B, L_0..L_{k-1}, R_0..R_{k-1}   compressed points (48 / 33 / 32 bytes each: BLS12-381 G1 ZCash form,
+ *                                                 SEC1, ristretto255)
+ *   r', s', delta'                                 32-byte little-endian scalars, canonical (< group order)
+ * Decoding rejects with BPP_FORMAT_ERROR (2): a wrong header, a malformed point encoding, a point off the curve, a point
+ * OUTSIDE THE PRIME-ORDER SUBGROUP (BLS12-381 G1 has a 126-bit cofactor: checked with the curve's endomorphism,
+ * csrc/ec.hpp aff_in_prime_subgroup), a non-canonical scalar.  Host pointers. */
+size_t bpp_proof_bytes(int curve_id, size_t n, size_t m);
+int bpp_proofs_encode(bpp_ctx *ctx, size_t n, size_t m, const uint64_t *points, const uint64_t *scalars, size_t count,
+                      uint8_t *out);
+/* out_points: count x (3 + 2k) wire points (infinity where an encoding was rejected); out_status: 0 / BPP_FORMAT_ERROR */
+int bpp_proofs_decode(bpp_ctx *ctx, size_t n, size_t m, const uint8_t *in, size_t count, uint64_t *out_points,
+                      uint64_t *out_scalars, uint32_t *out_status);
+/* RangeProof::verify for `count` serialized proofs: proofs count x bpp_proof_bytes, commitments count x m compressed
+ * points.  transcript != 0: challenges from the Fiat-Shamir transcript instead of the reference's constants.
+ * out_ok[p] = 0 Ok / 1 VerificationError / 2 FormatError. */
+int bpp_range_verify_batch_serialized(bpp_verifier *v, const uint8_t *proofs, const uint8_t *commitments, size_t count,
+                                      int transcript, uint32_t *out_ok);
 
 /* name of the kernel that dominates bpp_verifier_run (for profilers) and its launch geometry */
 const char *bpp_verifier_dominant_kernel(void);

@@ -1,0 +1,150 @@
+"""-m gpu: serialized proofs (the container), ristretto255 and the G1 subgroup check on the device against their
+restatements in oracle/pyref.py.  No reference counterpart (no serialization, no Ristretto in the reference): parity
+unpinned; pinned by the standard generator encodings and the restatements."""
+
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle as O
+import pyref as P
+from gpu_util import need_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ristretto255_codec_on_device():
+    need_gpu()
+    import bulletproofsplus_amd as B
+    R = P.Ristretto255
+    G = P.EdwardsGroup(P.ED25519)
+    a = B.Arith.init("ed25519")
+    assert B.compressed_bytes(a) == 32
+    Bp = G.base()
+    ks = [0, 1, 2, 3, 7, 1000003, P.ED25519["r"] - 1]
+    pts = [G.mul(Bp, k) if k else None for k in ks]
+    T4 = (R.SQRT_M1, 0)
+    pts += [G.add(pts[3], T4), G.add(pts[4], (0, R.P - 1))]          # other representatives of 3B and 7B
+    wire = O.points_to_wire(O.ED25519, pts)
+    enc = B.compress_points(a, wire)
+    assert bytes(enc[0]) == bytes(32)
+    assert bytes(enc[1]).hex() == "e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"     # RFC 9496 A.1
+    assert bytes(enc[2]).hex() == "6a493210f7499cd17fecb510ae0cea23a110e8d5b901f8acadd3095c73a3b919"
+    for i, pt in enumerate(pts):
+        assert bytes(enc[i]) == R.encode(pt)
+    assert bytes(enc[7]) == bytes(enc[3]) and bytes(enc[8]) == bytes(enc[4])
+    dec, ok = B.decompress_points(a, enc)
+    assert ok.tolist() == [0] * len(pts)
+    for i, pt in enumerate(pts):
+        got = O.wire_to_point(O.ED25519, dec[i])
+        exp = R.decode(R.encode(pt))
+        assert (got if got is not None else (0, 1)) == exp
+    bad = np.stack([np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8),            # negative s
+                    np.frombuffer(R.P.to_bytes(32, "little"), dtype=np.uint8),           # non-canonical
+                    np.frombuffer(hashlib.sha256(b"x").digest(), dtype=np.uint8)])
+    _, okb = B.decompress_points(a, bad)
+    assert okb.tolist()[:2] == [1, 1] and okb.tolist()[2] == (0 if R.decode(hashlib.sha256(b"x").digest()) else 1)
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("secp256k1", 1), ("ed25519", 2)])
+def test_container_encode_decode_verify(cname, cid):
+    need_gpu()
+    import bulletproofsplus_amd as B
+    c = P.CURVES[cname]
+    G = P.make_group(cname, False)
+    n, m = 4, 2
+    a = B.Arith.init(cname)
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=4)
+    vals = [[9, 3], [15, 0], [1, 2]]
+    gams = [[5, 6], [7, 8], [9, 10]]
+    pts, scs, V = bv.prove_batch(vals, gams)
+    blobs = B.encode_proofs(a, n, m, pts, scs)
+    assert blobs.shape == (3, B.proof_bytes(a, n, m))
+    # the device encoder == the restatement's, proof by proof
+    for i in range(3):
+        _, prover, proof = P.prove_case(cname, n, vals[i], gams[i], shadow=False)
+        assert bytes(blobs[i]) == P.encode_proof(c, n, m, proof)
+        assert P.decode_proof(c, G, n, m, bytes(blobs[i])) is not None
+    dp, ds, st = B.decode_proofs(a, n, m, blobs)
+    assert st.tolist() == [0, 0, 0] and np.array_equal(ds, scs)
+    if cname != "ed25519":
+        assert np.array_equal(dp, pts)
+    comm = B.compress_points(a, V.reshape(-1, a.PW)).reshape(3, m, -1)
+    assert bv.verify_serialized(blobs, comm).tolist() == [0, 0, 0]
+    # rejections: header, scalar range, point encoding, and a tampered scalar (VerificationError, not FormatError)
+    bad = blobs.copy()
+    bad[0, 4] = 2                                                            # version
+    r_le = np.frombuffer(c["r"].to_bytes(32, "little"), dtype=np.uint8)
+    bad[1, -32:] = r_le                                                      # delta' = r: not canonical
+    bad[2, -64] ^= 1                                                         # s' off by one: parses, fails the MulVec
+    assert bv.verify_serialized(bad, comm).tolist() == [2, 2, 1]
+    _, _, st = B.decode_proofs(a, n, m, bad)
+    assert st.tolist() == [2, 2, 0]
+    bad = blobs.copy()
+    cb = B.compressed_bytes(a)
+    if cname == "bls12_381":
+        bad[0, 12:12 + cb] = np.frombuffer(P.compress_point(c, (0, 2)), dtype=np.uint8)   # on the curve, order 3: outside G1
+        bad[1, 12] &= 0x7F                                                                # "uncompressed" flag
+    elif cname == "secp256k1":
+        bad[0, 12] = 4
+        bad[1, 13:13 + 32] = 0xFF                                                         # x >= p
+    else:
+        bad[0, 12] |= 1                                                                   # negative s
+        bad[1, 12:12 + cb] = np.frombuffer(R_P_BYTES, dtype=np.uint8)
+    assert bv.verify_serialized(bad, comm).tolist() == [2, 2, 0]
+    # a commitment that does not parse is a FormatError of its proof
+    cbad = comm.copy()
+    cbad[2, 1] = 0xFF
+    assert bv.verify_serialized(blobs, cbad).tolist() == [0, 0, 2]
+    bv.close()
+
+
+R_P_BYTES = ((1 << 255) - 19).to_bytes(32, "little")
+
+
+def test_bls12_381_subgroup_check_on_device():
+    """decode with the subgroup check: G1 points pass; curve points outside G1 (random, pure torsion, G1 + torsion) are
+    rejected exactly when [r] P != O."""
+    need_gpu()
+    import random
+    import bulletproofsplus_amd as B
+    c = P.BLS12_381
+    p, r = c["p"], c["r"]
+    G = P.WeierstrassGroup(c)
+    a = B.Arith.init("bls12_381")
+    rng = random.Random(9)
+    g = G.base()
+    pts, exp = [], []
+    for _ in range(4):
+        while True:
+            x = rng.randrange(p)
+            rhs = (x ** 3 + 4) % p
+            y = pow(rhs, (p + 1) // 4, p)
+            if y * y % p == rhs:
+                break
+        Pt = (x, y)
+        T = G.mul(Pt, r)
+        for cand in (Pt, T, G.add(G.mul(g, rng.randrange(r)), T), G.mul(g, rng.randrange(r))):
+            if cand is not None:
+                pts.append(cand)
+                exp.append(0 if G.is_zero(G.mul(cand, r)) else 1)
+    pts.append((0, 2))
+    exp.append(1)
+    assert 0 in exp and 1 in exp
+    # through the container decoder (the path that applies the check): put each point in the A slot of a valid proof
+    n, m = 4, 2
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=4)
+    ppts, pscs, _ = bv.prove_batch([[9, 3]], [[5, 6]])
+    blob = B.encode_proofs(a, n, m, ppts, pscs)[0]
+    blobs = np.stack([blob] * len(pts))
+    for i, pt in enumerate(pts):
+        blobs[i, 12:60] = np.frombuffer(P.compress_point(c, pt), dtype=np.uint8)
+    _, _, st = B.decode_proofs(a, n, m, blobs)
+    assert st.tolist() == [2 * e for e in exp]
+    # the plain codec (no subgroup check) accepts every curve point
+    _, ok = B.decompress_points(a, np.stack([np.frombuffer(P.compress_point(c, pt), dtype=np.uint8) for pt in pts]))
+    assert ok.tolist() == [0] * len(pts)
+    bv.close()
