@@ -242,6 +242,21 @@ class PublicKey:
         return cls(arith, length)
 
     @classmethod
+    def hashed(cls, arith: Arith, length: int, label: bytes = b"") -> "PublicKey":
+        """Generators hashed to the group from `label` (g stays the base point): what a deployment uses instead of the
+        reference's test generators.  No reference counterpart (include/bpp_amd.h, bpp_pk_hashed)."""
+        self = cls.__new__(cls)
+        self.arith = arith
+        PW = arith.PW
+        self.gh = np.zeros((2, PW), dtype=np.uint64)
+        G = np.zeros((max(length, 1), PW), dtype=np.uint64)
+        H = np.zeros((max(length, 1), PW), dtype=np.uint64)
+        check(_lib.lib().bpp_pk_hashed(arith.handle, bytes(label), len(label), length, _ptr(self.gh), _ptr(G), _ptr(H)),
+              "bpp_pk_hashed")
+        self.G_vec, self.H_vec = G[:length], H[:length]
+        return self
+
+    @classmethod
     def from_points(cls, arith: Arith, gh, G_vec, H_vec) -> "PublicKey":
         """An arbitrary generator set (the reference only has `new`; used for the 'hard' distribution)."""
         self = cls.__new__(cls)

@@ -73,6 +73,16 @@ extern "C" int bpp_pk_new(bpp_ctx* ctx, size_t length, uint64_t* out_gh, uint64_
     });
 }
 
+extern "C" int bpp_pk_hashed(bpp_ctx* ctx, const uint8_t* label, size_t label_len, size_t length, uint64_t* out_gh,
+                             uint64_t* out_G, uint64_t* out_H) {
+    if (!ctx || !out_gh || (label_len && !label) || (length && (!out_G || !out_H))) return fail(BPP_E_ARG, "null argument");
+    if (length > (1u << 24)) return fail(BPP_E_ARG, "length too large");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::pk_hashed(label, label_len, length, out_gh, out_G, out_H);
+    });
+}
+
 extern "C" int bpp_commit(bpp_ctx* ctx, const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out) {
     if (!ctx || !gh || !gamma || !out) return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));

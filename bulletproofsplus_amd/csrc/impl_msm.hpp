@@ -2,6 +2,7 @@
 // curve (tu_msm_*.hip).  Serves bpp_msm, bpp_msm_batch, bpp_scalar_mul_batch, bpp_pk_new, bpp_commit,
 // bpp_range_verify (single proof, no tables) and the device unit-test hooks.
 #pragma once
+#include "hash_to_group.hpp"
 #include "host_util.hpp"
 #include "pippenger.hpp"
 
@@ -88,6 +89,8 @@ struct MsmImpl {
 
     // PublicKey::new (publickey.rs:21-48)
     static int pk_new(size_t length, uint64_t* out_gh, uint64_t* out_G, uint64_t* out_H);
+    static int pk_hashed(const uint8_t* label, size_t label_len, size_t length, uint64_t* out_gh, uint64_t* out_G,
+                         uint64_t* out_H);
 
     // RangeProver::commit (prover.rs:28-42)
     static int commit(const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out);
@@ -242,6 +245,30 @@ int MsmImpl<C>::pk_new(size_t length, uint64_t* out_gh, uint64_t* out_G, uint64_
     return BPP_OK;
 }
 
+// g = the base point; h, G_i, H_i hashed to the group (hash_to_group.hpp): nobody knows their discrete logarithms
+template <class C>
+int MsmImpl<C>::pk_hashed(const uint8_t* label, size_t label_len, size_t length, uint64_t* out_gh, uint64_t* out_G,
+                          uint64_t* out_H) {
+    const size_t total = 1 + 2 * length;
+    const H2gSeed seed = h2g_seed(C::ID, label, label_len);
+    DevBuf dw;
+    HIPCHK(dw.alloc(total * WW * 4));
+    hipLaunchKernelGGL(k_hash_to_group<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, seed, (uint32_t)length, dw.u32());
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> hw(total * WW);
+    HIPCHK(hipMemcpy(hw.data(), dw.p, hw.size() * 4, hipMemcpyDeviceToHost));
+    uint32_t gw[WW];
+    aff_to_wire(aff_generator<C>(), gw);
+    const size_t pb = WW * 4;
+    std::memcpy(out_gh, gw, pb);
+    std::memcpy(reinterpret_cast<uint8_t*>(out_gh) + pb, hw.data(), pb);
+    if (length) {
+        std::memcpy(out_G, hw.data() + WW, length * pb);
+        std::memcpy(out_H, hw.data() + (1 + length) * WW, length * pb);
+    }
+    return BPP_OK;
+}
+
 template <class C>
 int MsmImpl<C>::commit(const uint64_t* gh, uint64_t v, const uint64_t* gamma, uint64_t* out) {
     uint32_t sc[16];
@@ -301,7 +328,17 @@ int MsmImpl<C>::range_verify_single(const uint64_t* gh, const uint64_t* G, const
     std::vector<uint64_t> res(PW);
     rc = msm_batch_dev(dsc.u32(), dpt.u32(), off, res.data(), nullptr);
     if (rc) return rc;
-    return res[PW - 1] ? BPP_OK : BPP_VERIFICATION_ERROR;
+    bool identity = res[PW - 1] != 0;
+    if constexpr (C::ID == 2) {
+        // the identity of ristretto255's quotient group: x = 0 or y = 0 (ristretto.hpp ed_is_identity_class)
+        bool x0 = true, y0 = true;
+        for (int i = 0; i < PW / 2; i++) {
+            x0 = x0 && res[i] == 0;
+            y0 = y0 && res[PW / 2 + i] == 0;
+        }
+        identity = identity || x0 || y0;
+    }
+    return identity ? BPP_OK : BPP_VERIFICATION_ERROR;
 }
 
 template <class C>

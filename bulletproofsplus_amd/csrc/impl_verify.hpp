@@ -269,7 +269,7 @@ int VerifyImpl<C>::create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t
         hipLaunchKernelGGL(k_tbl_fill<C>, dim3(cdiv(total, 64)), dim3(64), 0, nullptr, s, v->table.u32(),
                            tbl_scratch.u32(), f0, f1);
     }
-    tr_initial_state(C::ID, s.n, s.m, reinterpret_cast<const uint32_t*>(fixed.data()), fixed.size() * 2, v->tr0.st);
+    tr_initial_state<C>(s.n, s.m, reinterpret_cast<const uint32_t*>(fixed.data()), s.NF, v->tr0.st);
     std::vector<uint32_t> ch;
     default_challenges(s, ch);
     e = v->challenges.alloc(ch.size() * 4);

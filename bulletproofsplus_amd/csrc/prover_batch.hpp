@@ -406,8 +406,8 @@ __global__ void __launch_bounds__(64) k_pb_fs_yz(VerifyShape s, TranscriptState 
     if (p >= count) return;
     Transcript t;
     for (int i = 0; i < 8; i++) t.st[i] = st0.st[i];
-    for (uint32_t j = 0; j < s.m; j++) tr_append_words(t, tr_tag('V'), out_V + (p * s.m + j) * WW, WW);
-    tr_append_words(t, tr_tag('A'), out_points + p * (size_t)(3 + 2 * s.k) * WW, WW);
+    for (uint32_t j = 0; j < s.m; j++) tr_append_point<C>(t, tr_tag('V'), out_V + (p * s.m + j) * WW);
+    tr_append_point<C>(t, tr_tag('A'), out_points + p * (size_t)(3 + 2 * s.k) * WW);
     uint32_t w[8];
     uint32_t* c = ch + p * (size_t)(3 + s.k) * 8;
     fe_to_canonical(tr_challenge<P>(t, tr_tag('y')), w);
@@ -433,8 +433,8 @@ __global__ void __launch_bounds__(64) k_pb_fs_round(VerifyShape s, uint32_t t, c
     Transcript tr;
     for (int i = 0; i < 8; i++) tr.st[i] = tr_st[p * 8 + i];
     const uint32_t* rec = out_points + p * (size_t)(3 + 2 * k) * WW;
-    tr_append_words(tr, tr_tag('L'), rec + (size_t)(3 + t) * WW, WW);
-    tr_append_words(tr, tr_tag('R'), rec + (size_t)(3 + k + t) * WW, WW);
+    tr_append_point<C>(tr, tr_tag('L'), rec + (size_t)(3 + t) * WW);
+    tr_append_point<C>(tr, tr_tag('R'), rec + (size_t)(3 + k + t) * WW);
     const Fe<P> e = tr_challenge<P>(tr, tr_tag('e'));
     for (int i = 0; i < 8; i++) tr_st[p * 8 + i] = tr.st[i];
     uint32_t w[8];
@@ -458,8 +458,8 @@ __global__ void __launch_bounds__(64) k_pb_fs_final(VerifyShape s, const uint32_
     Transcript tr;
     for (int i = 0; i < 8; i++) tr.st[i] = tr_st[p * 8 + i];
     const uint32_t* rec = out_points + p * (size_t)(3 + 2 * k) * WW;
-    tr_append_words(tr, tr_tag('w', 'A'), rec + (size_t)1 * WW, WW);
-    tr_append_words(tr, tr_tag('w', 'B'), rec + (size_t)2 * WW, WW);
+    tr_append_point<C>(tr, tr_tag('w', 'A'), rec + (size_t)1 * WW);
+    tr_append_point<C>(tr, tr_tag('w', 'B'), rec + (size_t)2 * WW);
     const Fe<P> e = tr_challenge<P>(tr, tr_tag('e'));
     uint32_t w[8];
     fe_to_canonical(e, w);

@@ -19,13 +19,18 @@
 //                            little-endian 256-bit integers (512 bits reduced: the bias is below 2^-250)
 //   st0 = SHA-256("BulletproofsPlus-AMD transcript v1" || curve id, n, m as u32 LE || SHA-256(pk wire bytes))
 //         -- computed once per verifier on the host; binds curve, shape and generators
-// Sequence for one proof (points as the (2L+1) x u64 wire words of include/bpp_amd.h, little-endian):
+// A point enters as its canonical byte string: for the Weierstrass curves the (2L+1) x u64 wire words of
+// include/bpp_amd.h (affine coordinates are unique); for the Edwards instantiation the 32-byte ristretto255 encoding
+// -- an element there is a coset with four affine representatives, and prover and verifier need not hold the same one
+// (a decoded proof carries the decoder's representative).
+// Sequence for one proof:
 //   append("V", V_0) .. append("V", V_{m-1});  append("A", A);  y = challenge("y");  z = challenge("z")
 //   append("dsep", "wipp v1\0");  append("n", mn as u64)         (the separator sketched at wip.rs:339-348)
 //   per round t: append("L", L_t); append("R", R_t); e_t = challenge("e")
 //   append("wA", wip.A); append("wB", wip.B); e = challenge("e")
 // A challenge that reduces to zero (probability 2^-255) is replaced by one.
 #pragma once
+#include "ristretto.hpp"
 #include "sha256.hpp"
 
 namespace bpp {
@@ -68,6 +73,27 @@ BPP_HD_NOINLINE void tr_append_words(Transcript& t, uint32_t tag, const uint32_t
     tr_begin(s, t, tag, 4 * nwords);
     for (uint32_t i = 0; i < nwords; i++) sha256_word_le(s, words[i]);
     sha256_final(s, t.st);
+}
+
+// st <- H(st, tag, canonical bytes of the point given by its wire words)
+template <class C>
+BPP_HD void tr_append_point(Transcript& t, uint32_t tag, const uint32_t* wire) {
+    constexpr int N = C::Fp::N;
+    if constexpr (C::ID == 2) {
+        Aff<C> a = aff_inf<C>();
+        if (!(wire[2 * N] | wire[2 * N + 1])) {
+            a.x = fe_from_canonical<typename C::Fp>(wire);
+            a.y = fe_from_canonical<typename C::Fp>(wire + N);
+        }
+        uint8_t enc[32];
+        rist_encode(jac_from_aff(a), enc);
+        uint32_t w[8];
+        for (int i = 0; i < 8; i++)
+            w[i] = (uint32_t)enc[4 * i] | ((uint32_t)enc[4 * i + 1] << 8) | ((uint32_t)enc[4 * i + 2] << 16) | ((uint32_t)enc[4 * i + 3] << 24);
+        tr_append_words(t, tag, w, 8);
+    } else {
+        tr_append_words(t, tag, wire, 2 * N + 2);
+    }
 }
 
 BPP_HD void tr_append_u64(Transcript& t, uint32_t tag, uint64_t x) {
@@ -118,8 +144,8 @@ BPP_HD void tr_verifier_challenges(const uint32_t st0[8], const uint32_t* rec, u
     Transcript t;
 #pragma unroll
     for (int i = 0; i < 8; i++) t.st[i] = st0[i];
-    for (uint32_t j = 0; j < m; j++) tr_append_words(t, tr_tag('V'), rec + (size_t)(3 + 2 * k + j) * WW, WW);
-    tr_append_words(t, tr_tag('A'), rec, WW);
+    for (uint32_t j = 0; j < m; j++) tr_append_point<C>(t, tr_tag('V'), rec + (size_t)(3 + 2 * k + j) * WW);
+    tr_append_point<C>(t, tr_tag('A'), rec);
     uint32_t w[8];
     fe_to_canonical(tr_challenge<P>(t, tr_tag('y')), w);
     for (int i = 0; i < 8; i++) out[i] = w[i];
@@ -129,23 +155,39 @@ BPP_HD void tr_verifier_challenges(const uint32_t st0[8], const uint32_t* rec, u
     tr_append_words(t, tr_tag('d', 's', 'e', 'p'), dsep, 2);
     tr_append_u64(t, tr_tag('n'), mn);
     for (uint32_t r = 0; r < k; r++) {
-        tr_append_words(t, tr_tag('L'), rec + (size_t)(3 + r) * WW, WW);
-        tr_append_words(t, tr_tag('R'), rec + (size_t)(3 + k + r) * WW, WW);
+        tr_append_point<C>(t, tr_tag('L'), rec + (size_t)(3 + r) * WW);
+        tr_append_point<C>(t, tr_tag('R'), rec + (size_t)(3 + k + r) * WW);
         fe_to_canonical(tr_challenge<P>(t, tr_tag('e')), w);
         for (int i = 0; i < 8; i++) out[(size_t)(3 + r) * 8 + i] = w[i];
     }
-    tr_append_words(t, tr_tag('w', 'A'), rec + (size_t)1 * WW, WW);
-    tr_append_words(t, tr_tag('w', 'B'), rec + (size_t)2 * WW, WW);
+    tr_append_point<C>(t, tr_tag('w', 'A'), rec + (size_t)1 * WW);
+    tr_append_point<C>(t, tr_tag('w', 'B'), rec + (size_t)2 * WW);
     fe_to_canonical(tr_challenge<P>(t, tr_tag('e')), w);
     for (int i = 0; i < 8; i++) out[16 + i] = w[i];
 }
 
-// st0 on the host: SHA-256(domain || curve, n, m || SHA-256(pk wire words))
-inline void tr_initial_state(int curve_id, uint32_t n, uint32_t m, const uint32_t* pk_words, size_t pk_nwords,
-                             uint32_t st0[8]) {
+// st0 on the host: SHA-256(domain || curve, n, m || SHA-256(canonical bytes of g, h, G_0.., H_0..)); pk_wire: npts wire points
+template <class C>
+inline void tr_initial_state(uint32_t n, uint32_t m, const uint32_t* pk_wire, size_t npts, uint32_t st0[8]) {
+    constexpr int N = C::Fp::N;
+    constexpr int WW = 2 * N + 2;
     Sha256 s;
     sha256_init(s);
-    for (size_t i = 0; i < pk_nwords; i++) sha256_word_le(s, pk_words[i]);
+    for (size_t p = 0; p < npts; p++) {
+        const uint32_t* w = pk_wire + p * WW;
+        if constexpr (C::ID == 2) {
+            Aff<C> a = aff_inf<C>();
+            if (!(w[2 * N] | w[2 * N + 1])) {
+                a.x = fe_from_canonical<typename C::Fp>(w);
+                a.y = fe_from_canonical<typename C::Fp>(w + N);
+            }
+            uint8_t enc[32];
+            rist_encode(jac_from_aff(a), enc);
+            sha256_update(s, enc, 32);
+        } else {
+            for (int i = 0; i < WW; i++) sha256_word_le(s, w[i]);
+        }
+    }
     uint32_t pkd[8];
     sha256_final(s, pkd);
     static const char dom[] = "BulletproofsPlus-AMD transcript v1";   // 34 bytes + 2 bytes of zero padding = 36
@@ -153,7 +195,7 @@ inline void tr_initial_state(int curve_id, uint32_t n, uint32_t m, const uint32_
     for (size_t i = 0; i < sizeof(dom) - 1; i++) sha256_byte(s, (uint8_t)dom[i]);
     sha256_byte(s, 0);
     sha256_byte(s, 0);
-    sha256_word_le(s, (uint32_t)curve_id);
+    sha256_word_le(s, (uint32_t)C::ID);
     sha256_word_le(s, n);
     sha256_word_le(s, m);
     for (int i = 0; i < 8; i++) sha256_word_be(s, pkd[i]);

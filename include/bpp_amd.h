@@ -87,6 +87,14 @@ int bpp_scalar_mul_batch(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *
  * H_i = 5(i+1) g.  out_gh: 2 points [g, h]; out_G, out_H: `length` points each. */
 int bpp_pk_new(bpp_ctx *ctx, size_t length, uint64_t *out_gh, uint64_t *out_G, uint64_t *out_H);
 
+/* The production counterpart of PublicKey::new: g = the base point, h, G_i, H_i hashed to the group from `label`
+ * (csrc/hash_to_group.hpp), so that no discrete-log relation between the generators is known.  The reference only has
+ * the test generators above (its own comment at src/publickey.rs:23-39).  Not a standard hash-to-curve suite: try-and-
+ * increment (+ cofactor clearing on BLS12-381 G1) for the Weierstrass curves, RFC 9496 element derivation for
+ * ristretto255.  PARITY UNPINNED; restated in oracle/pyref.py. */
+int bpp_pk_hashed(bpp_ctx *ctx, const uint8_t *label, size_t label_len, size_t length, uint64_t *out_gh,
+                  uint64_t *out_G, uint64_t *out_H);
+
 /* RangeProver::commit / PublicKey::commitment (src/range/prover.rs:28-42, src/publickey.rs:50-52):
  * out = g * new(v as i32) + h * gamma.  The `v as i32` truncation of prover.rs:37 is kept. */
 int bpp_commit(bpp_ctx *ctx, const uint64_t *gh, uint64_t v, const uint64_t *gamma, uint64_t *out);

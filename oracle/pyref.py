@@ -475,8 +475,19 @@ class FsTranscript:
         return self
 
     def point_bytes(self, P) -> bytes:
+        """canonical bytes of a point in the transcript: wire words for the Weierstrass curves, the ristretto255
+        encoding for the Edwards instantiation (an element there has four affine representatives)"""
+        if self.curve["name"] == "ed25519":
+            return Ristretto255.encode(P)
         nb = 8 * self.L
-        if P is None or (self.curve["name"] == "ed25519" and P == (0, 1)):
+        if P is None:
+            return bytes(2 * nb) + (1).to_bytes(8, "little")
+        return P[0].to_bytes(nb, "little") + P[1].to_bytes(nb, "little") + bytes(8)
+
+    def wire_bytes(self, P) -> bytes:
+        """the C ABI's wire image of a point (what a proof record holds), whatever the transcript hashes"""
+        nb = 8 * self.L
+        if P is None:
             return bytes(2 * nb) + (1).to_bytes(8, "little")
         return P[0].to_bytes(nb, "little") + P[1].to_bytes(nb, "little") + bytes(8)
 
@@ -1148,3 +1159,37 @@ def decode_proof(curve: dict, G, n: int, m: int, data: bytes):
     if any(x >= curve["r"] for x in sc):
         return None
     return RangeProof(pts[0], WeightedInnerProductProof(pts[3:3 + k], pts[3 + k:3 + 2 * k], pts[1], pts[2], *sc))
+
+
+# --------------------------------------------------------------------------------------
+# Hashed generators -- TEST ORACLE for bulletproofsplus_amd/csrc/hash_to_group.hpp (no reference counterpart: the
+# reference's PublicKey::new only has test generators, publickey.rs:23-39)
+# --------------------------------------------------------------------------------------
+def hash_to_group(curve: dict, G, label: bytes, kind: str, idx: int):
+    import hashlib
+    cid = CURVE_IDS[curve["name"]]
+    seed = hashlib.sha256(b"BulletproofsPlus-AMD generators v1\0\0" + cid.to_bytes(4, "little") + label).digest()
+
+    def H(ctr, half):
+        return hashlib.sha256(seed + b"bppg" + ord(kind).to_bytes(4, "little") + idx.to_bytes(4, "little") +
+                              ctr.to_bytes(4, "little") + half.to_bytes(4, "little")).digest()
+
+    if curve["name"] == "ed25519":
+        return Ristretto255.from_uniform_bytes(H(0, 0) + H(0, 1), G)
+    p, b = curve["p"], curve["b"]
+    ctr = 0
+    while True:
+        x = (int.from_bytes(H(ctr, 0), "little") + (int.from_bytes(H(ctr, 1), "little") << 256)) % p
+        rhs = (x * x * x + b) % p
+        y = pow(rhs, (p + 1) // 4, p)
+        if y * y % p == rhs:
+            if (y & 1) != (H(ctr, 2)[0] & 1):
+                y = p - y
+            P = (x, y)
+            if curve["name"] == "bls12_381":
+                P = G.mul(P, 0xd201000000010001)
+                if P is None:
+                    ctr += 1
+                    continue
+            return P
+        ctr += 1

@@ -56,11 +56,17 @@ int main(int argc, char** argv) {
         fclose(f);
         const uint32_t curve = hdr[0], n = hdr[1], m = hdr[2], k = hdr[3];
         uint32_t st0[8];
-        tr_initial_state((int)curve, n, m, pk.data(), pk.size(), st0);
         std::vector<uint32_t> out((size_t)(3 + k) * 8);
-        if (curve == 0) tr_verifier_challenges<Bls12381>(st0, rec.data(), k, m, n * m, out.data());
-        else if (curve == 1) tr_verifier_challenges<Secp256k1>(st0, rec.data(), k, m, n * m, out.data());
-        else tr_verifier_challenges<Ed25519>(st0, rec.data(), k, m, n * m, out.data());
+        if (curve == 0) {
+            tr_initial_state<Bls12381>(n, m, pk.data(), pk.size() / (2 * BlsFp::N + 2), st0);
+            tr_verifier_challenges<Bls12381>(st0, rec.data(), k, m, n * m, out.data());
+        } else if (curve == 1) {
+            tr_initial_state<Secp256k1>(n, m, pk.data(), pk.size() / (2 * SecpFp::N + 2), st0);
+            tr_verifier_challenges<Secp256k1>(st0, rec.data(), k, m, n * m, out.data());
+        } else {
+            tr_initial_state<Ed25519>(n, m, pk.data(), pk.size() / (2 * EdFp::N + 2), st0);
+            tr_verifier_challenges<Ed25519>(st0, rec.data(), k, m, n * m, out.data());
+        }
         for (int i = 0; i < 8; i++) printf("%08x\n", st0[i]);
         for (uint32_t w : out) printf("%08x\n", w);
         return 0;

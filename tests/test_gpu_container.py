@@ -148,3 +148,37 @@ def test_bls12_381_subgroup_check_on_device():
     _, ok = B.decompress_points(a, np.stack([np.frombuffer(P.compress_point(c, pt), dtype=np.uint8) for pt in pts]))
     assert ok.tolist() == [0] * len(pts)
     bv.close()
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1", "ed25519"])
+def test_hashed_generators(cname):
+    """PublicKey.hashed: == the restatement; on the curve, in the prime-order group, pairwise distinct; label-separated;
+    and a range proof over them proves and verifies (constants and transcript mode)."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    c = P.CURVES[cname]
+    cid = O.CURVE_IDS[cname]
+    G = P.make_group(cname, False)
+    a = B.Arith.init(cname)
+    n, m = 4, 2
+    pk = B.PublicKey.hashed(a, n * m, b"test generators")
+    assert O.wire_to_point(cid, pk.gh[0]) == G.base()
+    exp = [P.hash_to_group(c, G, b"test generators", "h", 0)] + \
+          [P.hash_to_group(c, G, b"test generators", "G", i) for i in range(n * m)] + \
+          [P.hash_to_group(c, G, b"test generators", "H", i) for i in range(n * m)]
+    got = [O.wire_to_point(cid, w) for w in [pk.gh[1]] + list(pk.G_vec) + list(pk.H_vec)]
+    assert got == exp
+    assert len(set(got)) == len(got) and all(G.on_curve(q) for q in got)
+    for q in got[:3]:
+        L = G.mul(q, c["r"])
+        assert L is None or (cname == "ed25519" and (L[0] == 0 or L[1] == 0))
+    pk2 = B.PublicKey.hashed(a, n * m, b"another label")
+    assert not np.array_equal(pk2.G_vec, pk.G_vec)
+    bv = B.BatchVerifier(pk, n, m, window_bits=4)
+    for fs in (False, True):
+        pts, scs, V = bv.prove_batch([[9, 3], [15, 1]], [[5, 6], [7, 8]], transcript=fs)
+        blobs = B.encode_proofs(a, n, m, pts, scs)
+        comm = B.compress_points(a, V.reshape(-1, a.PW)).reshape(2, m, -1)
+        assert bv.verify_serialized(blobs, comm, transcript=fs).tolist() == [0, 0]
+        assert bv.verify_serialized(blobs, comm, transcript=not fs).tolist() == [1, 1]
+    bv.close()

@@ -46,7 +46,7 @@ def _words(b):
 
 
 @pytest.mark.parametrize("curve,cid,n,vals", [("secp256k1", 1, 8, [200, 5]), ("bls12_381", 0, 4, [9]),
-                                              ("secp256k1", 1, 4, [3, 7, 1, 15])])
+                                              ("secp256k1", 1, 4, [3, 7, 1, 15]), ("ed25519", 2, 4, [9, 3])])
 def test_transcript_matches_hashlib_restatement(harness, curve, cid, n, vals):
     m = len(vals)
     G = P.make_group(curve, False)
@@ -63,8 +63,8 @@ def test_transcript_matches_hashlib_restatement(harness, curve, cid, n, vals):
     w = proof.proof
     k = len(w.L_vec)
     rec = [proof.A, w.A, w.B] + list(w.L_vec) + list(w.R_vec) + list(prover.commitment_vec)
-    recb = b"".join(fs.point_bytes(pt) for pt in rec)
-    pkb = b"".join(fs.point_bytes(pt) for pt in [pk.g, pk.h] + list(pk.G_vec) + list(pk.H_vec))
+    recb = b"".join(fs.wire_bytes(pt) for pt in rec)
+    pkb = b"".join(fs.wire_bytes(pt) for pt in [pk.g, pk.h] + list(pk.G_vec) + list(pk.H_vec))
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
         f.write(struct.pack("<6I", cid, n, m, k, len(pkb) // 4, len(recb) // 4) + pkb + recb)
         path = f.name
