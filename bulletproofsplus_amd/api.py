@@ -166,6 +166,22 @@ def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
     return out
 
 
+def wip_fold_round(arith: Arith, a, b, G, H, y_nhat, e):
+    """One folding round of WeightedInnerProductProof::prove (wip.rs:147-164).  a, b: (len, 4) scalars; G, H: (len, PW)
+    points.  Returns the folded (a, b, G, H) of length len / 2."""
+    aw = np.ascontiguousarray(scalars_to_wire(a)).copy()
+    bw = np.ascontiguousarray(scalars_to_wire(b)).copy()
+    Gw = np.ascontiguousarray(G, dtype=np.uint64).reshape(-1, arith.PW).copy()
+    Hw = np.ascontiguousarray(H, dtype=np.uint64).reshape(-1, arith.PW).copy()
+    n = aw.shape[0]
+    if not (bw.shape[0] == Gw.shape[0] == Hw.shape[0] == n):
+        raise AssertionError("wip fold: vector lengths must match")          # wip.rs:60-67 asserts
+    check(_lib.lib().bpp_wip_fold_round(arith.handle, _ptr(aw), _ptr(bw), _ptr(Gw), _ptr(Hw), n,
+                                        _ptr(scalar_to_wire(y_nhat)), _ptr(scalar_to_wire(e))), "bpp_wip_fold_round")
+    h = n // 2
+    return aw[:h], bw[:h], Gw[:h], Hw[:h]
+
+
 def compressed_bytes(arith: Arith) -> int:
     """bytes of one compressed point (48 BLS12-381 G1, 33 secp256k1 SEC1; 0 = not offered)"""
     return _lib.lib().bpp_point_compressed_bytes(arith.curve)

@@ -112,6 +112,15 @@ extern "C" int bpp_range_prove(bpp_ctx* ctx, const uint64_t* gh, const uint64_t*
     });
 }
 
+extern "C" int bpp_wip_fold_round(bpp_ctx* ctx, uint64_t* a, uint64_t* b, uint64_t* G, uint64_t* H, size_t len,
+                                  const uint64_t* y_nhat, const uint64_t* e) {
+    if (!ctx || !a || !b || !G || !H || !y_nhat || !e) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return ProveImpl<decltype(cv)>::wip_fold_round(a, b, G, H, len, y_nhat, e);
+    });
+}
+
 // ---- batch verifier ------------------------------------------------------------------------------------
 extern "C" int bpp_verifier_create(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
                                    size_t m, int window_bits, bpp_verifier** out) {

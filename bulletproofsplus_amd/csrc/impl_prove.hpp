@@ -50,6 +50,8 @@ struct HostFr {
 
 template <class C>
 struct ProveImpl {
+static int wip_fold_round(uint64_t* a, uint64_t* b, uint64_t* G, uint64_t* H, size_t len, const uint64_t* y_nhat,
+                          const uint64_t* e);
 static int range_prove(const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n, size_t m,
                      const uint64_t* v, const uint64_t* gamma, const uint64_t* V, uint64_t* out_points,
                      uint64_t* out_scalars, std::string& err);
@@ -281,6 +283,57 @@ HF::to_words(r_prime, os);
 HF::to_words(s_prime, os + 8);
 HF::to_words(d_prime, os + 16);
 return BPP_OK;
+}
+
+// One folding round of WeightedInnerProductProof::prove as a seam of its own (reference wip.rs:147-164), host buffers,
+// in place on the first len / 2 entries:
+//   a[i] <- a[i] e + a[n' + i] y^n' e^-1        b[i] <- b[i] e^-1 + b[n' + i] e
+//   G[i] <- e^-1 G[i] + y^-n' e G[n' + i]       H[i] <- e H[i] + e^-1 H[n' + i]                        n' = len / 2
+template <class C>
+int ProveImpl<C>::wip_fold_round(uint64_t* a, uint64_t* b, uint64_t* G, uint64_t* H, size_t len, const uint64_t* y_nhat,
+                                 const uint64_t* e_in) {
+    using P = typename C::Fr;
+    using F = Fe<P>;
+    using HF = HostFr<C>;
+    constexpr int N = C::Fp::N;
+    constexpr int PW = (2 * N + 2) / 2;
+    if (len < 2 || (len & (len - 1))) return fail(BPP_E_ARG, "len must be a power of two >= 2");
+    const size_t nn = len / 2;
+    const F e = HF::from_words(reinterpret_cast<const uint32_t*>(e_in));
+    const F yh = HF::from_words(reinterpret_cast<const uint32_t*>(y_nhat));
+    if (e.is_zero() || yh.is_zero()) return fail(BPP_E_ARG, "the challenge and y^n' must be invertible");
+    const F e_inv = fe_inv(e), yh_inv = fe_inv(yh);
+    const F yh_e_inv = fe_mul(yh, e_inv), yh_inv_e = fe_mul(yh_inv, e);
+    uint32_t* aw = reinterpret_cast<uint32_t*>(a);
+    uint32_t* bw = reinterpret_cast<uint32_t*>(b);
+    for (size_t i = 0; i < nn; i++) {
+        const F a1 = HF::from_words(aw + i * 8), a2 = HF::from_words(aw + (nn + i) * 8);
+        const F b1 = HF::from_words(bw + i * 8), b2 = HF::from_words(bw + (nn + i) * 8);
+        HF::to_words(fe_add(fe_mul(a1, e), fe_mul(a2, yh_e_inv)), aw + i * 8);
+        HF::to_words(fe_add(fe_mul(b1, e_inv), fe_mul(b2, e)), bw + i * 8);
+    }
+    DevBuf dG, dH, dsc, dw;
+    int rc = upload_points<C>(G, len, dG, nullptr);
+    if (rc) return rc;
+    rc = upload_points<C>(H, len, dH, nullptr);
+    if (rc) return rc;
+    uint32_t fsc[32];
+    HF::to_words(e_inv, fsc);
+    HF::to_words(yh_inv_e, fsc + 8);
+    HF::to_words(e, fsc + 16);
+    HF::to_words(e_inv, fsc + 24);
+    HIPCHK(dsc.alloc(sizeof fsc));
+    HIPCHK(hipMemcpy(dsc.p, fsc, sizeof fsc, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fold_points<C>, dim3(cdiv(2 * nn, 64)), dim3(64), 0, nullptr, dG.u32(), dH.u32(), (uint32_t)nn,
+                       dsc.u32());
+    HIPCHK(hipGetLastError());
+    HIPCHK(dw.alloc(nn * (2 * N + 2) * 4));
+    for (int which = 0; which < 2; which++) {
+        hipLaunchKernelGGL(k_points_to_wire<C>, dim3(cdiv(nn, 64)), dim3(64), 0, nullptr, which ? dH.u32() : dG.u32(), dw.u32(), nn);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(which ? H : G, dw.p, nn * PW * 8, hipMemcpyDeviceToHost));
+    }
+    return BPP_OK;
 }
 
 #endif  // BPP_IMPL_DEFINITIONS

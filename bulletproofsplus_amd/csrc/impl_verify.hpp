@@ -50,10 +50,13 @@ constexpr unsigned fixed_lds() {
     return std::max<unsigned>(fixed_lds_bytes<C>(), FIXED_BLOCK * jac_words<C>() * 4);
 }
 
-// The wave-per-proof (tree) Horner is used for a single chain only: a lone proof, and the one Horner of the combined
-// check.  With more tree waves the dispatcher packs them onto shared SIMDs and every chain slows down again
-// (2 proofs: 5.8 ms against 4.3 ms for one; 16 proofs: 6.7 ms against 5.7 ms with one lane per proof).
-constexpr size_t HORNER_TREE_MAX = 1;
+// The wave-per-proof (tree) Horner serves the batches too small to fill the chip: one block per proof, so that the
+// chains spread over the CUs (with two tree waves per block they slowed each other down: 5.8 ms for 2 proofs against
+// 4.3 ms for one).  Above HORNER_TREE_MAX proofs the one-lane-per-proof form rides beside the fixed-generator blocks.
+#ifndef BPP_HORNER_TREE_MAX
+#define BPP_HORNER_TREE_MAX 256
+#endif
+constexpr size_t HORNER_TREE_MAX = BPP_HORNER_TREE_MAX;
 constexpr unsigned FOLD_GROUP = 8;    // thread partials summed by one lane of k_partials_fold (first pass)
 constexpr unsigned FOLD_GROUP2 = 4;   // ... and of the second pass
 
@@ -334,7 +337,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
     // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree)
     const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
-    const unsigned hb = tree ? cdiv(count, FIXED_BLOCK / 64) : cdiv(count, FIXED_BLOCK);
+    const unsigned hb = tree ? (unsigned)count : cdiv(count, FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
     hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
                        w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u});

@@ -108,6 +108,15 @@ int bpp_range_prove(bpp_ctx *ctx, const uint64_t *gh, const uint64_t *G, const u
                     size_t m, const uint64_t *v, const uint64_t *gamma, const uint64_t *V,
                     uint64_t *out_points, uint64_t *out_scalars);
 
+/* One folding round of WeightedInnerProductProof::prove as a seam of its own (src/weighted_inner_product_proof.rs:147-164),
+ * in place on the first n' = len / 2 entries of each array (host pointers; a, b: len scalars; G, H: len points):
+ *   a[i] = a[i] e + a[n'+i] y^n' e^-1 ;  b[i] = b[i] e^-1 + b[n'+i] e ;
+ *   G[i] = MulVec[e^-1, y^-n' e].[G[i], G[n'+i]] ;  H[i] = MulVec[e, e^-1].[H[i], H[n'+i]]
+ * y_nhat = y^n' (wip.rs:98), e = the round's challenge (wip.rs:131).  bpp_range_prove runs this per round on resident
+ * vectors; the batched prover (bpp_range_prove_batch) never folds points at all (csrc/prover_batch.hpp). */
+int bpp_wip_fold_round(bpp_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t *G, uint64_t *H, size_t len,
+                       const uint64_t *y_nhat, const uint64_t *e);
+
 /* RangeProof::verify (src/range/mod.rs:57-78 -> verify_single :189-238 + wip verify
  * src/weighted_inner_product_proof.rs:238-328, or verify_multiple :405-510).
  * proof_points as written by bpp_range_prove with k rounds.  Returns 0 / 1 / negative. */

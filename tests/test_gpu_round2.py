@@ -361,3 +361,35 @@ def test_fs_prover_reference_size_64x16():
     ok, _, _ = run_verifier_device(torch, bv, recs, bad, want_scalars=False, want_result=False, challenges=ch)
     assert ok.tolist() == [0, 0, 0, 0, 1, 0]
     bv.close()
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1"])
+def test_wip_fold_round_seam(cname):
+    """bpp_wip_fold_round == one round of the big-integer restatement's fold (wip.rs:147-164)."""
+    need_gpu()
+    import bulletproofsplus_amd as B
+    cid = O.CURVE_IDS[cname]
+    c = P.CURVES[cname]
+    r = c["r"]
+    G_ = P.make_group(cname, False)
+    a = B.Arith.init(cname)
+    n = 8
+    pk = P.PublicKey(G_, n)
+    rs = np.random.RandomState(4)
+    av = [int(x) * 0x1234567 % r for x in rs.randint(1, 2**31, size=n)]
+    bv_ = [int(x) * 0x7654321 % r for x in rs.randint(1, 2**31, size=n)]
+    y, e = 12, 7
+    y_nhat = pow(y, n // 2, r)
+    e_inv, yi = pow(e, -1, r), pow(y_nhat, -1, r)
+    h = n // 2
+    exp_a = [(av[i] * e + av[h + i] * y_nhat * e_inv) % r for i in range(h)]
+    exp_b = [(bv_[i] * e_inv + bv_[h + i] * e) % r for i in range(h)]
+    exp_G = [G_.add(G_.mul(pk.G_vec[i], e_inv), G_.mul(pk.G_vec[h + i], yi * e % r)) for i in range(h)]
+    exp_H = [G_.add(G_.mul(pk.H_vec[i], e), G_.mul(pk.H_vec[h + i], e_inv)) for i in range(h)]
+    fa, fb, fG, fH = B.wip_fold_round(a, av, bv_, O.points_to_wire(cid, list(pk.G_vec)), O.points_to_wire(cid, list(pk.H_vec)),
+                                      y_nhat, e)
+    assert O.wire_to_scalars(fa) == exp_a and O.wire_to_scalars(fb) == exp_b
+    assert O.wire_to_points(cid, fG) == exp_G and O.wire_to_points(cid, fH) == exp_H
+    with pytest.raises(B.BppError):
+        B.wip_fold_round(a, av[:6], bv_[:6], O.points_to_wire(cid, list(pk.G_vec[:6])), O.points_to_wire(cid, list(pk.H_vec[:6])),
+                         y_nhat, e)
