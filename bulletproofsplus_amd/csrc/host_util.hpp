@@ -200,6 +200,24 @@ inline int make_shape(size_t n, size_t m, int c, const uint32_t* fr_modw, int fr
     return BPP_OK;
 }
 
+// the two verifier-scalars kernels (kernels.hpp): d_prep holds count * vs_prep_bytes<C>(s) bytes
+template <class C>
+inline int launch_verify_scalars(const VerifyShape& s, const uint32_t* d_proof_scalars, const uint32_t* d_challenges,
+                                 uint32_t ch_stride, uint32_t* d_out, size_t count, uint32_t* d_prep, hipStream_t st) {
+    static bool lds_opted_in = false;   // above the default dynamic-LDS limit: opt in once (160 KB per CU on gfx950)
+    if (vs_lds_bytes<C>(s) > 64 * 1024 && !lds_opted_in) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vs_expand<C>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
+        lds_opted_in = true;
+    }
+    hipLaunchKernelGGL(k_vs_prepare<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, s, d_proof_scalars, d_challenges, ch_stride,
+                       d_prep, d_out, count);
+    hipLaunchKernelGGL(k_vs_expand<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s, d_prep, d_out,
+                       count);
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
 // default challenges = the reference's hard-coded "transcript" (SURVEY.md 3.4):
 // [y, z, e, e_1..e_k] = m == 1 ? [7, 7, 99, 7..] : [12, 23, 99, 7..]
 inline void default_challenges(const VerifyShape& s, std::vector<uint32_t>& w) {

@@ -318,11 +318,10 @@ int MsmImpl<C>::range_verify_single(const uint64_t* gh, const uint64_t* G, const
     HIPCHK(dch.alloc(ch.size() * 4));
     HIPCHK(hipMemcpy(dch.p, ch.data(), ch.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(dsc.alloc((size_t)s.N * 32));
-    if (vs_lds_bytes<C>(s) > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_verify_scalars<C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
-    hipLaunchKernelGGL(k_verify_scalars<C>, dim3(1), dim3(VS_BLOCK), vs_lds_bytes<C>(s), nullptr, s, dps.u32(), dch.u32(), 0u,
-                       dsc.u32(), (size_t)1);
+    DevBuf dprep;
+    HIPCHK(dprep.alloc(vs_prep_bytes<C>(s)));
+    rc = launch_verify_scalars<C>(s, dps.u32(), dch.u32(), 0u, dsc.u32(), (size_t)1, dprep.u32(), nullptr);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> off = {0, s.N};
     std::vector<uint64_t> res(PW);

@@ -61,7 +61,7 @@ constexpr unsigned FOLD_GROUP = 8;    // thread partials summed by one lane of k
 constexpr unsigned FOLD_GROUP2 = 4;   // ... and of the second pass
 
 struct WsLayout {
-    size_t pts, bad, scalars, fthread, fpart, fpart2, fpart3, vpart, vdig, vwsum, vtbl, vscr, total;
+    size_t pts, bad, scalars, prep, fthread, fpart, fpart2, fpart3, vpart, vdig, vwsum, vtbl, vscr, total;
 };
 
 template <class C>
@@ -81,6 +81,8 @@ struct VerifyImpl {
         o += al(count * 4);
         w.scalars = o;
         o += al(count * (size_t)s.N * 32);
+        w.prep = o;
+        o += al(count * vs_prep_bytes<C>(s));                      // per-proof constants of the verifier-scalars kernels
         w.fthread = o;
         o += al(count * blocks_per_proof(s, count) * FIXED_BLOCK * JW * 4);                // one partial per thread
         w.fpart = o;
@@ -115,7 +117,7 @@ struct VerifyImpl {
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
-        size_t pts, bad, scalars, weights, comb_sc, fpart, var_sc, vdig, vtbl, vscr, vwsum, vfold, total;
+        size_t pts, bad, scalars, prep, weights, comb_sc, fpart, var_sc, vdig, vtbl, vscr, vwsum, vfold, total;
         unsigned fixed_blocks;
     };
     static constexpr uint32_t COMB_FOLD_GROUP = 4;    // proofs whose window sums one lane of k_comb_window_fold adds
@@ -131,6 +133,8 @@ struct VerifyImpl {
         o += al(count * 4);
         w.scalars = o;
         o += al(count * (size_t)s.N * 32);
+        w.prep = o;
+        o += al(count * vs_prep_bytes<C>(s));
         w.weights = o;
         o += al(count * 32);
         w.comb_sc = o;
@@ -241,11 +245,6 @@ int VerifyImpl<C>::create(const bpp_ctx& ctx, const uint64_t* gh, const uint64_t
     DevBuf dfixed;
     rc = upload_points<C>(fixed.data(), s.NF, dfixed, nullptr);
     if (rc) return rc;
-    if (vs_lds_bytes<C>(s) > 64 * 1024) {
-        // above the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_verify_scalars<C>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds_bytes<C>(s)));
-    }
     bpp_verifier* v = new bpp_verifier();
     v->ctx = ctx;
     v->s = s;
@@ -319,8 +318,11 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     HIPCHK(mark(2 * BPP_STAGE_SCALARS, st));
-    hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
-                       reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
+    {
+        int rc_vs = launch_verify_scalars<C>(s, reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count,
+                                             reinterpret_cast<uint32_t*>(ws + L.prep), st);
+        if (rc_vs) return rc_vs;
+    }
     HIPCHK(mark(2 * BPP_STAGE_SCALARS + 1, st));
     // proof-point MSM: digits, per-point tables, window sums (all arithmetic bound, so they simply run in
     // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
@@ -406,8 +408,11 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
-    hipLaunchKernelGGL(k_verify_scalars<C>, dim3(cdiv(count, VS_PB)), dim3(VS_BLOCK), vs_lds_bytes<C>(s), st, s,
-                       reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count);
+    {
+        int rc_vs = launch_verify_scalars<C>(s, reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count,
+                                             reinterpret_cast<uint32_t*>(ws + L.prep), st);
+        if (rc_vs) return rc_vs;
+    }
     WeightKey wk;
     for (int i = 0; i < 8; i++)
         wk.w[i] = d_weights ? 0u

@@ -15,7 +15,7 @@
 //   k_scalar_mul         n independent Point * scalar          point/point.rs:69-85, publickey.rs:21-48
 //   k_msm_naive_partial  MulVec::calculate, one scalar-mul per thread + block reduce   mulvec.rs:20-33
 //   k_jac_reduce         sums jacobian partials of one MulVec -> wire point
-//   k_verify_scalars     all verifier scalars of one proof      wip.rs:330-382, range/mod.rs:417-477, :198-226,
+//   k_vs_prepare/expand  all verifier scalars of one proof      wip.rs:330-382, range/mod.rs:417-477, :198-226,
 //                                                               wip.rs:254-295
 //   k_fixed_msm          the 2mn+2 fixed-generator terms of the final MulVec via window tables (XYZZ sums, LDS-DMA
 //                        gather ring, one partial per thread); its leading blocks run the Horner lanes of the
@@ -37,7 +37,7 @@ namespace bpp {
 // launch geometry (threads per block) of the heavy kernels; the __launch_bounds__ below let the register
 // allocator use the whole 512-entry VGPR file at that occupancy instead of the 1024-thread default (128)
 constexpr unsigned MSM_BLOCK = 64;
-constexpr unsigned VS_PB = 8;                 // proofs per block of k_verify_scalars, 64 lanes each
+constexpr unsigned VS_PB = 8;                 // proofs per block of k_vs_expand, 64 lanes each
 constexpr unsigned VS_BLOCK = VS_PB * 64;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
@@ -262,7 +262,8 @@ __device__ Fe<P> sum_of_powers(const Fe<P>& x, uint32_t n, bool type2) {
 #define VS_MAXN 64
 #define VS_MAXCH 64   // indices per lane = mn / 64 (<= n)
 
-// per-proof scratch of k_verify_scalars, carved from dynamic LDS (sizes depend on k, m, mn/64)
+// per-proof scratch of the verifier-scalars kernels: a block of `prep` in HBM (k_vs_prepare) that k_vs_expand copies
+// into dynamic LDS (sizes depend on k, m, mn/64)
 template <class F>
 struct VsShared {
     F* chsq;      // [k]    e_j^2
@@ -299,7 +300,7 @@ struct VsShared {
     __device__ F& einv() { return c[6]; }
 };
 
-// dynamic LDS bytes of one k_verify_scalars block (Fr elements are NL 32-bit words each)
+// dynamic LDS bytes of one k_vs_expand block (Fr elements are NL 32-bit words each)
 template <class C>
 inline size_t vs_lds_bytes(const VerifyShape& s) {
     using F = Fe<typename C::Fr>;
@@ -307,24 +308,183 @@ inline size_t vs_lds_bytes(const VerifyShape& s) {
     return ((size_t)VS_MAXN + (size_t)VS_PB * VsShared<F>::elems(s.k, s.m, CH)) * sizeof(F);
 }
 
-// VS_PB proofs per block, 64 lanes per proof.  Writes the N MulVec scalars of each proof (canonical, 8
-// words each) in the reference's MulVec order:
+// The verifier's scalars in two kernels.  Writes the N MulVec scalars of each proof (canonical, 8 words each) in
+// the reference's MulVec order:
 //   m > 1 (range/mod.rs:481-490): [1, e^-1, e^-2, g_exp, h_exp, e_i^2 (k), e_i^-2 (k), G_exp (mn), H_exp (mn), V_exp (m)]
 //   m = 1 (wip.rs:298-307)      : [1, e,    e^2,  g_exp, h_exp, e_i^2 e^2,  e_i^-2 e^2, G_exp (n),  H_exp (n),  V_exp (1)]
-// proof_scalars: [r', s', delta'] per proof; challenges: [y, z, e, e_1..e_k] (per proof when
-// ch_stride != 0, shared otherwise).
-// Phases: (A) one lane per proof inverts y, e, e_1..e_k with ONE inversion (fe_inv: safegcd; Montgomery's trick for the rest);
-// (B) one lane per proof computes the per-proof constants, another the power tables; (B') the first
-// mn/64 lanes of each proof build three small per-proof tables; (C) 64 lanes per proof, mn/64 consecutive
-// indices each, three multiplications per index:
+// proof_scalars: [r', s', delta'] per proof; challenges: [y, z, e, e_1..e_k] (per proof when ch_stride != 0, shared
+// otherwise).
+//   k_vs_prepare (ONE LANE PER PROOF): what is serial per proof -- the inversion of y, e, e_1..e_k with ONE safegcd call
+//     (Montgomery's trick for the rest), the per-proof constants and head scalars (~150 dependent Fr products), the
+//     power tables y^(2^b), y^-(2^b) -- into a per-proof block of `prep`.  Every lane of every wave works on its own
+//     proof; in round 1 this ran on one or two lanes of a 512-thread block while the other 500 waited, and the
+//     kernel was latency bound (1.4 ms per 8192 proofs against ~0.3 ms of arithmetic).
+//   k_vs_expand (VS_PB proofs per block, 64 lanes per proof, mn/64 consecutive indices each): copies the proofs'
+//     blocks into LDS, builds three small per-proof tables, then three multiplications per index:
 //   G_exp[i] = cG - [kG allinv prod_{hi bits} e^2 y^-(i0+1)] * sy_lo[l]                (range/mod.rs:456-459)
 //   H_exp[i] = [pz y^(mn-i0) 2^(i0%n) cH] * t_lo[l] + z cH - [kH allinv prod_{hi unset} e^2] * sc_lo[l]   (:461-465)
 // with i = i0 + l, using s_vec[i] = allinv * prod_{bit b of i set} e^2_{k-1-b} (wip.rs:372-380 unrolled).
 template <class C>
-__global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, const uint32_t* __restrict__ proof_scalars,
-                                                             const uint32_t* __restrict__ challenges,
-                                                             uint32_t ch_stride, uint32_t* __restrict__ out,
-                                                             size_t count) {
+inline size_t vs_prep_bytes(const VerifyShape& s) {
+    using F = Fe<typename C::Fr>;
+    const uint32_t CH = s.mn >= 64 ? s.mn / 64 : 1;
+    return (size_t)VsShared<F>::elems(s.k, s.m, CH) * sizeof(F);
+}
+
+template <class C>
+__global__ void __launch_bounds__(64) k_vs_prepare(VerifyShape s, const uint32_t* __restrict__ proof_scalars,
+                                                   const uint32_t* __restrict__ challenges, uint32_t ch_stride,
+                                                   uint32_t* __restrict__ prep, uint32_t* __restrict__ out, size_t count) {
+    using P = typename C::Fr;
+    using F = Fe<P>;
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    const uint32_t k = s.k, mn = s.mn;
+    const uint32_t CH = mn >= 64 ? mn / 64 : 1;
+    const uint32_t per_proof = VsShared<F>::elems(k, s.m, CH);
+    VsShared<F> sh(reinterpret_cast<F*>(prep) + b * per_proof, k, s.m, CH);
+    const uint32_t* ch = challenges + (size_t)ch_stride * b;
+    // ---- inverses of [y, e, e_1..e_k] ------------------------------------------------------------------
+    {
+        // order: x_0 = y, x_1 = e, x_{2+j} = e_j ; zero entries are skipped (their "inverse" stays 0)
+        F acc = F::one();
+        for (uint32_t j = 0; j < k + 2; j++) {
+            uint32_t w[8];
+            ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
+            F x = fe_from_canonical<P>(w);
+            if (!x.is_zero()) acc = fe_mul(acc, x);
+            sh.tmp[j] = acc;
+        }
+        F inv = fe_inv(acc);
+        for (uint32_t j = k + 2; j-- > 0;) {
+            uint32_t w[8];
+            ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
+            F x = fe_from_canonical<P>(w);
+            F xi = F::zero();
+            if (!x.is_zero()) {
+                xi = j ? fe_mul(inv, sh.tmp[j - 1]) : inv;
+                inv = fe_mul(inv, x);
+            }
+            if (j == 0) sh.yinv() = xi;
+            else if (j == 1) sh.einv() = xi;
+            else {
+                sh.chsq[j - 2] = fe_sqr(x);
+                sh.chinvsq[j - 2] = fe_sqr(xi);
+                sh.tmp[j] = xi;                        // e_{j-2}^-1 (slot j is no longer needed as a prefix)
+            }
+        }
+    }
+    // ---- per-proof constants and head scalars ------------------------------------------------------------
+    {
+        uint32_t* o = out + b * (size_t)s.N * 8;
+        uint32_t w[8];
+        ld_words<8>(ch + 0, w);
+        const F y = fe_from_canonical<P>(w);
+        ld_words<8>(ch + 8, w);
+        const F z = fe_from_canonical<P>(w);
+        ld_words<8>(ch + 16, w);
+        const F e = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24, w);
+        const F rp = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24 + 8, w);
+        const F sp = fe_from_canonical<P>(w);
+        ld_words<8>(proof_scalars + b * 24 + 16, w);
+        const F dp = fe_from_canonical<P>(w);
+        const F einv = sh.einv();
+        F allinv = F::one();                        // batch_invert's product of the e_j^-1
+        for (uint32_t j = 0; j < k; j++) allinv = fe_mul(allinv, sh.tmp[j + 2]);
+        const F zsq = fe_sqr(z);
+        F head1, head2, g_exp, h_exp, lr_mul, kG, kH, cH;
+        uint32_t wv[8];
+        if (s.m == 1) {
+            // range/mod.rs:198-226 + wip.rs:254-295
+            const F esq = fe_sqr(e);
+            head1 = e;
+            head2 = esq;
+            sh.cG() = fe_mul(fe_neg(z), esq);
+            kG = fe_mul(fe_mul(rp, e), y);
+            kH = fe_mul(sp, e);
+            cH = esq;
+            const F y_n1 = fe_pow_u64(y, (uint64_t)s.n + 1);
+            F gc = F::zero();  // sum_{i<n} y^{i+1}
+            {
+                F cur = y;
+                for (uint32_t i = 0; i < s.n; i++) {
+                    gc = fe_add(gc, cur);
+                    cur = fe_mul(cur, y);
+                }
+            }
+            gc = fe_mul(gc, fe_sub(z, zsq));
+            const F two = fe_from_u32<P>(2);
+            const F t = fe_sub(fe_pow_u64(two, s.n), F::one());
+            gc = fe_sub(gc, fe_mul(fe_mul(t, y_n1), z));
+            g_exp = fe_add(fe_mul(fe_mul(fe_neg(rp), y), sp), fe_mul(gc, esq));
+            h_exp = fe_neg(dp);
+            lr_mul = esq;
+            sh.pz[0] = F::one();
+            fe_to_canonical(fe_mul(y_n1, esq), wv);  // V_exp
+            st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn) * 8, wv);
+        } else {
+            // range/mod.rs:417-477
+            const F einv2 = fe_sqr(einv);  // == (e^2)^-1
+            head1 = einv;
+            head2 = einv2;
+            sh.cG() = fe_neg(z);
+            kG = fe_mul(fe_mul(rp, einv), y);
+            kH = fe_mul(sp, einv);
+            cH = F::one();
+            const F y_mn1 = fe_pow_u64(y, (uint64_t)mn + 1);
+            const F sum_y = sum_of_powers<P>(y, mn, true);
+            const F sum_2 = sum_of_powers<P>(fe_from_u32<P>(2), s.n, false);
+            const F sum_z = sum_of_powers<P>(zsq, s.m, true);
+            const F t1 = fe_mul(fe_mul(fe_mul(fe_neg(rp), sp), y), einv2);
+            const F t2 = fe_sub(fe_mul(sum_y, fe_sub(z, zsq)), fe_mul(fe_mul(fe_mul(y_mn1, z), sum_2), sum_z));
+            g_exp = fe_add(t1, t2);
+            h_exp = fe_mul(fe_neg(dp), einv2);
+            lr_mul = F::one();
+            F cur = zsq;
+            for (uint32_t j = 0; j < s.m; j++) {  // power_of_z and V_exp
+                sh.pz[j] = cur;
+                fe_to_canonical(fe_mul(cur, y_mn1), wv);
+                st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn + j) * 8, wv);
+                cur = fe_mul(cur, zsq);
+            }
+        }
+        sh.kGa() = fe_mul(kG, allinv);
+        sh.kHa() = fe_mul(kH, allinv);
+        sh.hmul() = cH;
+        sh.zc() = fe_mul(z, cH);
+        fe_to_canonical(F::one(), wv);
+        st_words<8>(o + 0, wv);
+        fe_to_canonical(head1, wv);
+        st_words<8>(o + 8, wv);
+        fe_to_canonical(head2, wv);
+        st_words<8>(o + 16, wv);
+        fe_to_canonical(g_exp, wv);
+        st_words<8>(o + 24, wv);
+        fe_to_canonical(h_exp, wv);
+        st_words<8>(o + 32, wv);
+        for (uint32_t j = 0; j < k; j++) {
+            fe_to_canonical(fe_mul(sh.chsq[j], lr_mul), wv);
+            st_words<8>(o + (size_t)(5 + j) * 8, wv);
+            fe_to_canonical(fe_mul(sh.chinvsq[j], lr_mul), wv);
+            st_words<8>(o + (size_t)(5 + k + j) * 8, wv);
+        }
+        // power tables y^(2^b), y^-(2^b)
+        F yy = y;
+        F yi = sh.yinv();
+        for (uint32_t bnum = 0; bnum <= k; bnum++) {
+            sh.ypw[bnum] = yy;
+            sh.yipw[bnum] = yi;
+            yy = fe_sqr(yy);
+            yi = fe_sqr(yi);
+        }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(VS_BLOCK) k_vs_expand(VerifyShape s, const uint32_t* __restrict__ prep,
+                                                        uint32_t* __restrict__ out, size_t count) {
     using P = typename C::Fr;
     using F = Fe<P>;
     extern __shared__ __align__(16) uint32_t lds_raw[];
@@ -338,169 +498,23 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
     const uint32_t per_proof = VsShared<F>::elems(k, s.m, CH);
     auto proof_lds = [&](uint32_t slot) { return VsShared<F>(lds_f + VS_MAXN + (size_t)slot * per_proof, k, s.m, CH); };
 
-    // ---- phase A: lanes 0..VS_PB-1 invert [y, e, e_1..e_k] of their proof; lanes 64.. build 2^t --------
-    if (tid < VS_PB) {
-        const size_t b = (size_t)blockIdx.x * VS_PB + tid;
-        if (b < count) {
-            VsShared<F> sh = proof_lds(tid);
-            const uint32_t* ch = challenges + (size_t)ch_stride * b;
-            // order: x_0 = y, x_1 = e, x_{2+j} = e_j ; zero entries are skipped (their "inverse" stays 0)
-            F acc = F::one();
-            for (uint32_t j = 0; j < k + 2; j++) {
-                uint32_t w[8];
-                ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
-                F x = fe_from_canonical<P>(w);
-                if (!x.is_zero()) acc = fe_mul(acc, x);
-                sh.tmp[j] = acc;
-            }
-            F inv = fe_inv(acc);
-            for (uint32_t j = k + 2; j-- > 0;) {
-                uint32_t w[8];
-                ld_words<8>(ch + (j == 0 ? 0 : (j == 1 ? 2 : 1 + j)) * 8, w);
-                F x = fe_from_canonical<P>(w);
-                F xi = F::zero();
-                if (!x.is_zero()) {
-                    xi = j ? fe_mul(inv, sh.tmp[j - 1]) : inv;
-                    inv = fe_mul(inv, x);
-                }
-                if (j == 0) sh.yinv() = xi;
-                else if (j == 1) sh.einv() = xi;
-                else {
-                    sh.chsq[j - 2] = fe_sqr(x);
-                    sh.chinvsq[j - 2] = fe_sqr(xi);
-                    sh.tmp[j] = xi;                        // e_{j-2}^-1 (slot j is no longer needed as a prefix)
-                }
-            }
-        }
-    } else if (tid >= 64 && tid < 64 + s.n && tid - 64 < VS_MAXN) {
-        const uint32_t t = tid - 64;
-        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        w[t >> 5] = 1u << (t & 31);
-        sh_p2[t] = fe_from_canonical<P>(w);
-    }
-    __syncthreads();
-
-    // ---- phase B: lane q: per-proof constants and head scalars; lane 64+q: power tables --------------
-    if (tid < VS_PB) {
-        const size_t b = (size_t)blockIdx.x * VS_PB + tid;
-        if (b < count) {
-            VsShared<F> sh = proof_lds(tid);
-            const uint32_t* ch = challenges + (size_t)ch_stride * b;
-            uint32_t* o = out + b * (size_t)s.N * 8;
-            uint32_t w[8];
-            ld_words<8>(ch + 0, w);
-            const F y = fe_from_canonical<P>(w);
-            ld_words<8>(ch + 8, w);
-            const F z = fe_from_canonical<P>(w);
-            ld_words<8>(ch + 16, w);
-            const F e = fe_from_canonical<P>(w);
-            ld_words<8>(proof_scalars + b * 24, w);
-            const F rp = fe_from_canonical<P>(w);
-            ld_words<8>(proof_scalars + b * 24 + 8, w);
-            const F sp = fe_from_canonical<P>(w);
-            ld_words<8>(proof_scalars + b * 24 + 16, w);
-            const F dp = fe_from_canonical<P>(w);
-            const F einv = sh.einv();
-            F allinv = F::one();                        // batch_invert's product of the e_j^-1
-            for (uint32_t j = 0; j < k; j++) allinv = fe_mul(allinv, sh.tmp[j + 2]);
-            const F zsq = fe_sqr(z);
-            F head1, head2, g_exp, h_exp, lr_mul, kG, kH, cH;
-            uint32_t wv[8];
-            if (s.m == 1) {
-                // range/mod.rs:198-226 + wip.rs:254-295
-                const F esq = fe_sqr(e);
-                head1 = e;
-                head2 = esq;
-                sh.cG() = fe_mul(fe_neg(z), esq);
-                kG = fe_mul(fe_mul(rp, e), y);
-                kH = fe_mul(sp, e);
-                cH = esq;
-                const F y_n1 = fe_pow_u64(y, (uint64_t)s.n + 1);
-                F gc = F::zero();  // sum_{i<n} y^{i+1}
-                {
-                    F cur = y;
-                    for (uint32_t i = 0; i < s.n; i++) {
-                        gc = fe_add(gc, cur);
-                        cur = fe_mul(cur, y);
-                    }
-                }
-                gc = fe_mul(gc, fe_sub(z, zsq));
-                const F two = fe_from_u32<P>(2);
-                const F t = fe_sub(fe_pow_u64(two, s.n), F::one());
-                gc = fe_sub(gc, fe_mul(fe_mul(t, y_n1), z));
-                g_exp = fe_add(fe_mul(fe_mul(fe_neg(rp), y), sp), fe_mul(gc, esq));
-                h_exp = fe_neg(dp);
-                lr_mul = esq;
-                sh.pz[0] = F::one();
-                fe_to_canonical(fe_mul(y_n1, esq), wv);  // V_exp
-                st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn) * 8, wv);
-            } else {
-                // range/mod.rs:417-477
-                const F einv2 = fe_sqr(einv);  // == (e^2)^-1
-                head1 = einv;
-                head2 = einv2;
-                sh.cG() = fe_neg(z);
-                kG = fe_mul(fe_mul(rp, einv), y);
-                kH = fe_mul(sp, einv);
-                cH = F::one();
-                const F y_mn1 = fe_pow_u64(y, (uint64_t)mn + 1);
-                const F sum_y = sum_of_powers<P>(y, mn, true);
-                const F sum_2 = sum_of_powers<P>(fe_from_u32<P>(2), s.n, false);
-                const F sum_z = sum_of_powers<P>(zsq, s.m, true);
-                const F t1 = fe_mul(fe_mul(fe_mul(fe_neg(rp), sp), y), einv2);
-                const F t2 = fe_sub(fe_mul(sum_y, fe_sub(z, zsq)), fe_mul(fe_mul(fe_mul(y_mn1, z), sum_2), sum_z));
-                g_exp = fe_add(t1, t2);
-                h_exp = fe_mul(fe_neg(dp), einv2);
-                lr_mul = F::one();
-                F cur = zsq;
-                for (uint32_t j = 0; j < s.m; j++) {  // power_of_z and V_exp
-                    sh.pz[j] = cur;
-                    fe_to_canonical(fe_mul(cur, y_mn1), wv);
-                    st_words<8>(o + (size_t)(5 + 2 * k + 2 * mn + j) * 8, wv);
-                    cur = fe_mul(cur, zsq);
-                }
-            }
-            sh.kGa() = fe_mul(kG, allinv);
-            sh.kHa() = fe_mul(kH, allinv);
-            sh.hmul() = cH;
-            sh.zc() = fe_mul(z, cH);
-            fe_to_canonical(F::one(), wv);
-            st_words<8>(o + 0, wv);
-            fe_to_canonical(head1, wv);
-            st_words<8>(o + 8, wv);
-            fe_to_canonical(head2, wv);
-            st_words<8>(o + 16, wv);
-            fe_to_canonical(g_exp, wv);
-            st_words<8>(o + 24, wv);
-            fe_to_canonical(h_exp, wv);
-            st_words<8>(o + 32, wv);
-            for (uint32_t j = 0; j < k; j++) {
-                fe_to_canonical(fe_mul(sh.chsq[j], lr_mul), wv);
-                st_words<8>(o + (size_t)(5 + j) * 8, wv);
-                fe_to_canonical(fe_mul(sh.chinvsq[j], lr_mul), wv);
-                st_words<8>(o + (size_t)(5 + k + j) * 8, wv);
-            }
-        }
-    } else if (tid >= 64 && tid < 64 + VS_PB) {
-        const uint32_t q = tid - 64;
-        const size_t b = (size_t)blockIdx.x * VS_PB + q;
-        if (b < count) {
-            VsShared<F> sh = proof_lds(q);
-            uint32_t w[8];
-            ld_words<8>(challenges + (size_t)ch_stride * b, w);
-            F y = fe_from_canonical<P>(w);
-            F yi = sh.yinv();
-            for (uint32_t bnum = 0; bnum <= k; bnum++) {  // y^(2^b), y^-(2^b)
-                sh.ypw[bnum] = y;
-                sh.yipw[bnum] = yi;
-                y = fe_sqr(y);
-                yi = fe_sqr(yi);
-            }
+    // ---- the proofs' prepared blocks: global -> LDS (word by word, coalesced); 2^t table ---------------------
+    {
+        const size_t first = (size_t)blockIdx.x * VS_PB;
+        const size_t nproofs = count - first < VS_PB ? count - first : VS_PB;
+        const size_t words = nproofs * per_proof * (sizeof(F) / 4);
+        const uint32_t* src = prep + first * per_proof * (sizeof(F) / 4);
+        uint32_t* dst = lds_raw + VS_MAXN * (sizeof(F) / 4);
+        for (size_t t = tid; t < words; t += blockDim.x) dst[t] = src[t];
+        if (tid < s.n && tid < VS_MAXN) {
+            uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            w[tid >> 5] = 1u << (tid & 31);
+            sh_p2[tid] = fe_from_canonical<P>(w);
         }
     }
     __syncthreads();
 
-    // ---- phase B': low-bit tables, lane l < CH of each proof -----------------------------------------
+    // ---- low-bit tables, lane l < CH of each proof -----------------------------------------------------
     const uint32_t q = tid / 64, lane = tid % 64;
     const size_t b = (size_t)blockIdx.x * VS_PB + q;
     const bool active = b < count;
@@ -522,7 +536,7 @@ __global__ void __launch_bounds__(VS_BLOCK) k_verify_scalars(VerifyShape s, cons
     }
     __syncthreads();
 
-    // ---- phase C --------------------------------------------------------------------------------------
+    // ---- three multiplications per index -----------------------------------------------------------------
     if (!active) return;
     const uint32_t i0 = lane * CH;
     if (i0 >= mn) return;
