@@ -374,6 +374,38 @@ BPP_HD void fe_mul_wide(const Fe<P>& a, const Fe<P>& b, uint32_t* T) {
 // against 338 v_mad + 60 v_lshl_add_u64 + 48 shifts + 51 masks + 25 v_mov + 13 v_mul_lo of the two-pass form
 // as the compiler scheduled it.
 //   col(k, acc): adds the plain products of column k (k <= 2NL-2) to acc.
+// acc += a * b, and acc += a * k for a limb k of the modulus.
+// Tried and not kept (-DBPP_ASM_MAD): every multiply-add as inline asm pins the chain order completely (no
+// reassociation, no 64-bit merge adds) but the compiler pads almost every asm statement with an s_nop (it must assume
+// the gfx940 dst-forwarding hazard), and on MI355X those nops cost what the merges cost: fe_mul 80.3 vs 80.6 G/s, lazy
+// XYZZ addition 7.41 vs 7.66 G/s on the same box (tools/ubench.hip).
+// Kept for the sparse moduli only (P::SPARSE_MOD: secp256k1's 2^256 - 2^32 - 977 and 2^255 - 19, whose 30-bit limbs are
+// mostly all-ones): there the compiler strength-reduces m * 0x3fffffff into shifts, subtractions and 64-bit adds that
+// cost more issue slots than the multiply-add they replace; the asm form keeps the v_mad_u64_u32 (+5 % on the
+// secp256k1 addition).
+BPP_HD void fe_mad(uint64_t& acc, uint32_t a, uint32_t b) {
+#if defined(BPP_ASM_MAD) && defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+    acc += (uint64_t)a * b;
+#endif
+}
+template <class P>
+BPP_HD void fe_mad_k(uint64_t& acc, uint32_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(BPP_ASM_MAD)
+    constexpr bool use_asm = true;
+#else
+    constexpr bool use_asm = P::SPARSE_MOD;
+#endif
+    if constexpr (use_asm) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+        return;
+    }
+#endif
+    acc += (uint64_t)a * k;
+}
+
 template <class P, int W, int K, class ColFn>
 BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t* m, Fe<P>& r, uint32_t one) {
     constexpr int NL = P::NL;
@@ -390,19 +422,19 @@ BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t
         const uint32_t T = (uint32_t)accA & LIMB_MASK;
         accA >>= LIMB_BITS;
         BPP_CHAIN_BARRIER(accA);
-        accB += (uint64_t)T * one;
+        fe_mad(accB, T, one);
     } else {
         if constexpr (prev_split) accB += accA;
         if constexpr (na > 0) col(K, accB);
     }
     if constexpr (K < NL) {
 #pragma unroll
-        for (int i = 0; i < K; i++) accB += (uint64_t)m[i] * P::MOD[K - i];
+        for (int i = 0; i < K; i++) fe_mad_k<P>(accB, m[i], P::MOD[K - i]);
         m[K] = ((uint32_t)accB * P::INV) & LIMB_MASK;
-        accB += (uint64_t)m[K] * P::MOD[0];
+        fe_mad_k<P>(accB, m[K], P::MOD[0]);
     } else {
 #pragma unroll
-        for (int i = K - NL + 1; i < NL; i++) accB += (uint64_t)m[i] * P::MOD[K - i];
+        for (int i = K - NL + 1; i < NL; i++) fe_mad_k<P>(accB, m[i], P::MOD[K - i]);
         r.l[K - NL] = (uint32_t)accB & LIMB_MASK;
     }
     accB >>= LIMB_BITS;
@@ -431,7 +463,7 @@ BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     constexpr int NL = P::NL;
     return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) fe_mad(acc, a.l[i], b.l[k - i]);
     });
 }
 
@@ -443,8 +475,8 @@ BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe
     return fe_fused_reduce<P, 2>([&](int k, uint64_t& acc) {
 #pragma unroll
         for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
+            fe_mad(acc, a.l[i], b.l[k - i]);
+            fe_mad(acc, c.l[i], d.l[k - i]);
         }
     });
 }
@@ -461,8 +493,8 @@ BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
     return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
         // pairs i < j, i + j = k
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) acc += (uint64_t)a.l[i] * a2[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) fe_mad(acc, a.l[i], a2[k - i]);
+        if ((k & 1) == 0) fe_mad(acc, a.l[k / 2], a.l[k / 2]);
     });
 }
 
