@@ -626,11 +626,15 @@ __device__ __forceinline__ void affine_chain(Jac<C> J, const Aff<C>& step, uint3
             ld_words<N>(scratch + (size_t)k * N, w);
             inv = fe_mul(inv, fe_load<P>(w));
         }
-        Jac<C> q = J;   // only X and Y are read by jac_scale_to_aff
+        // only X and Y are read by jac_scale_to_aff; the running point J must NOT be named here, or its 3 N registers
+        // stay alive across the inversion (that alone was most of this function's scratch spills)
+        Jac<C> q;
         ld_words<N>(out + (size_t)k * 2 * N, w);
         q.X = fe_load<P>(w);
         ld_words<N>(out + (size_t)k * 2 * N + N, w);
         q.Y = fe_load<P>(w);
+        q.Z = q.Y;
+        if constexpr (C::ID == 2) q.T = q.Y;
         aff_stg<C>(out + (size_t)k * 2 * N, jac_scale_to_aff(q, zi));
     }
 }
@@ -660,7 +664,9 @@ __host__ __device__ __forceinline__ uint32_t tbl_runs_per_generator(const Verify
     return (s.W - 1) * ((s.half + TBL_RUN - 1) / TBL_RUN) + (s.top + TBL_RUN - 1) / TBL_RUN;
 }
 template <class C>
-__global__ void __launch_bounds__(64, 2) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t* __restrict__ scratch,
+// one wave per SIMD: the chain of mixed additions plus the safegcd inversion needs ~300 registers; at the two-wave
+// budget of 256 it spilled 220 bytes to scratch
+__global__ void __launch_bounds__(64, 1) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t* __restrict__ scratch,
                                                     uint32_t f_begin, uint32_t f_end) {
     constexpr int N = C::Fp::N;
     const uint32_t runs_low = (s.half + TBL_RUN - 1) / TBL_RUN;
@@ -798,8 +804,14 @@ struct VpSel {
 // DMAs a dummy line -- so every step issues exactly 2N/4 DMA instructions per wave and a counted
 // s_waitcnt vmcnt((FIXED_RING-1) * 2N/4) is all the synchronisation the ring needs.  The next generator's
 // scalar travels the same way (2 pieces), one generator ahead.
+// waves per SIMD the register allocator must leave room for: two for the 13-limb field (219 VGPRs), three for the 9-limb
+// fields (158 / 145 VGPRs fit the 170 of a three-wave budget)
+template <class C>
+constexpr int fixed_waves() {
+    return C::Fp::NL > 9 ? BPP_FIXED_WAVES : 3;
+}
 template <class C, int ROLE = 0>
-__global__ void __launch_bounds__(FIXED_BLOCK, BPP_FIXED_WAVES) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
+__global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per,
                             uint32_t horner_blocks, const uint32_t* __restrict__ wsum, uint32_t* __restrict__ var_out,
                             size_t horner_count, uint32_t horner_tree, VpSel sel) {
@@ -1026,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
 // lane = (proof, point).  tables: [lane][8] affm.  scratch: [lane][14] field elements (Z_k and their prefix
 // products, k = 2..8).
 template <class C>
-__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_tables(const uint32_t* __restrict__ proof_pts,
+__global__ void __launch_bounds__(VAR_BLOCK, 1) k_var_tables(const uint32_t* __restrict__ proof_pts,
                                                                         uint32_t* __restrict__ tables,
                                                                         uint32_t* __restrict__ scratch, size_t lanes) {
     using P = typename C::Fp;

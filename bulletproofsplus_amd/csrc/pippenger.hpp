@@ -17,7 +17,7 @@
 //   k_pip_heavy / k_pip_heavy_fold   which split one bucket over PIP_SPLIT x 128 lanes
 //   k_pip_windows  per window: sum_k (k+1) * B_k  by per-thread running sums over bucket segments, a small
 //                  scalar multiplication for the segment offset, and an LDS tree over the block
-//   k_pip_final    Horner over the W window sums (c doublings between windows), written as a jacobian
+//   k_pip_final    Horner over the W window sums (one wave, a tree over the windows), written as a jacobian
 #pragma once
 #include <algorithm>
 
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipShape s, const uint32_t*
 // corner case: the top window of a scalar < 2^255 holds only a carry bit, so half of all points can land
 // in ONE bucket there.
 constexpr uint32_t PIP_HEAVY = 96;
-constexpr uint32_t PIP_WIN_BLOCK = 512;   // lanes per window in k_pip_windows (short segments: the kernel is latency bound)
+constexpr uint32_t PIP_WIN_BLOCK = 256;   // lanes per window in k_pip_windows (latency bound; at 512 lanes the 256-register budget spilled 140 B)
 constexpr uint32_t PIP_SPLIT = 16;
 
 // one thread per (window, bucket): bucket sum as a jacobian in buckets[j][b]
@@ -260,27 +260,44 @@ __global__ void __launch_bounds__(PIP_WIN_BLOCK) k_pip_windows(PipShape s, const
 }
 
 // Horner over the windows; the result is ADDED to `extra` partials (may be none) and written as one
-// jacobian to out.  A single lane: about 258 sequential doublings.
+// jacobian to out.  One wave, as a binary tree over the windows (W <= 37 for the c in [7, 16] pip_pick_c chooses): lane j starts with R_j;
+// at level l the lanes whose index is a multiple of 2^(l+1) take the partial of lane j + 2^l through LDS, double it
+// c * 2^l times and add it.  The ~c (W - 1) doublings of the top window still form one chain, but the W additions
+// of Horner's rule shrink to 6 on the critical path (the same form as var_horner_wave in kernels.hpp).
 template <class C>
 __global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __restrict__ window_sums,
                                                   const uint32_t* __restrict__ extra, uint32_t n_extra,
                                                   uint32_t* __restrict__ out) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    // Everything below depends only on kernel arguments, i.e. is wave-uniform, and hipcc would compile it
-    // to the SCALAR unit (s_mul_i32 / s_mul_hi_u32 / s_addc_u32: ~4 instructions per limb product).  An
-    // opaque per-lane zero in the addresses keeps the chain on the vector unit (v_mad_u64_u32).
-    uint32_t lane_zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-    window_sums += lane_zero;
+    __shared__ __align__(16) uint32_t lds[64 * JW];
+    if (blockIdx.x != 0) return;
+    const uint32_t j = threadIdx.x & 63u;
+    // G consecutive windows per lane (G = 1 unless an explicit narrow window gives W > 64), folded serially first
+    const uint32_t G = (s.W + 63) / 64, L = (s.W + G - 1) / G;
     Jac<C> acc = jac_inf<C>();
-    for (uint32_t j = s.W; j-- > 0;) {
+    for (uint32_t g = G; g-- > 0;) {
+        const uint32_t w = j * G + g;
+        if (w >= s.W) continue;
         if (!acc.is_inf())
             for (uint32_t t = 0; t < s.c; t++) acc = jac_dbl(acc);
-        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)j * JW));
+        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)w * JW));
     }
-    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + lane_zero + (size_t)t * JW));
+    for (uint32_t stride = 1; stride < L; stride <<= 1) {
+        jac_store(acc, lds + (size_t)j * JW);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((j & (2 * stride - 1)) == 0 && j + stride < L) {
+            Jac<C> hi = jac_load<C>(lds + (size_t)(j + stride) * JW);
+            if (!hi.is_inf())
+                for (uint32_t t = 0; t < s.c * G * stride; t++) hi = jac_dbl(hi);
+            acc = jac_add(acc, hi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (j != 0) return;
+    for (uint32_t t = 0; t < n_extra; t++) acc = jac_add(acc, jac_ldg<C>(extra + (size_t)t * JW));
     jac_stg<C>(out, acc);
 }
 
