@@ -342,7 +342,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const unsigned hb = tree ? (unsigned)count : cdiv(count, FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
     hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                       w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u});
+                       w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u, 0u});
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
     // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
@@ -441,7 +441,7 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     // leading block; the Horner result lands behind the block sums
     hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
                        v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u,
-                       VpSel{1u, 0u, 1u});
+                       VpSel{1u, 0u, 1u, 0u});
     hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
                        d_out_partial);
     hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
@@ -493,7 +493,7 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
                                    W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
             hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, W(L.a), W(L.b),
                                W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
-            msm(VpSel{nvp, 0u, nvp});
+            msm(VpSel{nvp, 0u, nvp, 1u});
             continue;
         }
         uint32_t* o_ch = d_out_challenges ? reinterpret_cast<uint32_t*>(d_out_challenges) + base * (size_t)(3 + k) * 8
@@ -502,22 +502,22 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
         const unsigned lanes = cdiv(cnt, 64);
         hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
                            chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-        msm(VpSel{nvp, 0u, 1u});               // A
-        msm(VpSel{nvp, 2 * k + 3, m});         // V_0 .. V_{m-1}
+        msm(VpSel{nvp, 0u, 1u, 1u});              // A
+        msm(VpSel{nvp, 2 * k + 3, m, 1u});        // V_0 .. V_{m-1}
         hipLaunchKernelGGL(k_pb_fs_yz<C>, dim3(lanes), dim3(64), 0, st, s, v->tr0, o_pts, o_V, W(L.trst), o_ch, cnt);
         hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
                            chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
         for (uint32_t t = 0; t < k; t++) {
             hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
                                W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            msm(VpSel{nvp, 1 + 2 * t, 2u});    // L_t, R_t
+            msm(VpSel{nvp, 1 + 2 * t, 2u, 1u});   // L_t, R_t
             hipLaunchKernelGGL(k_pb_fs_round<C>, dim3(lanes), dim3(64), 0, st, s, t, o_pts, W(L.trst), o_ch, W(L.con), cnt);
             hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_POST, W(L.a),
                                W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
         }
         hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, W(L.a), W(L.b),
                            W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
-        msm(VpSel{nvp, 2 * k + 1, 2u});        // wip.A, wip.B
+        msm(VpSel{nvp, 2 * k + 1, 2u, 1u});       // wip.A, wip.B
         hipLaunchKernelGGL(k_pb_fs_final<C>, dim3(lanes), dim3(64), 0, st, s, o_pts, W(L.trst), o_ch, W(L.con), cnt);
         hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, W(L.a), W(L.b),
                            W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);

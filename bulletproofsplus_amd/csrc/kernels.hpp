@@ -783,8 +783,17 @@ constexpr unsigned fixed_lds_bytes() {
 // cnt = 1).  The batched prover keeps nvp "virtual proofs" per real proof (its L_t, R_t, A, B, commitments: each a
 // MulVec over the same fixed generators) and launches either all of them or, under the Fiat-Shamir transcript, the
 // cnt consecutive ones a step has just produced: flat index b of the launch -> array (b / cnt) * nvp + first + b % cnt.
+//
+// prover = 1 tells the kernel which virtual proof is which (prover_batch.hpp: 0 = range A, 1 + 2t / 2 + 2t = L_t / R_t,
+// 2k+1, 2k+2 = wip.A, wip.B, then the commitments), because most of them are sparse over the fixed generators in a way
+// that is known up front, and a lane that walks a zero scalar idles through 15 steps beside its busy neighbours:
+//   * L_t and R_t each use HALF of the G_j and the complementary half of the H_j (bit k-1-t of j decides,
+//     k_pb_round): their mn + 2 terms are enumerated densely, slot x -> generator by inserting that bit;
+//   * a commitment has two terms (g, h);
+//   * range A has scalars +1 (on G_j) or -1 (on H_j): -1 is a full-width scalar, 15 mixed additions for what is one
+//     subtraction -- k_pb_init stores +1 there and this kernel negates the table entry instead.
 struct VpSel {
-    uint32_t nvp, first, cnt;
+    uint32_t nvp, first, cnt, prover;
 };
 
 // Fixed-generator part: for proof b, sum_f scalar_f * F_f through the window tables.
@@ -846,19 +855,43 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
     const uint32_t sbuf_addr = ring_addr + FIXED_RING * CH * 1024;
     const uint32_t f0 = part * blockDim.x + threadIdx.x;   // the lane's index among the proof's `stride` lanes
     const uint32_t first = part * blockDim.x;
+    // dense enumeration of the generators this MulVec can have non-zero scalars on (block-uniform; see VpSel)
+    uint32_t NFc = s.NF, cmode = 0, cbit = 0, neg_from = 0xffffffffu;
+    if (sel.prover) {
+        const uint32_t vp = sel.first + (uint32_t)(b % sel.cnt);
+        if (vp == 0) {
+            neg_from = 2 + s.mn;
+        } else if (vp <= 2 * s.k) {
+            cmode = 1 + ((vp - 1) & 1u);          // 1: L_t, 2: R_t
+            cbit = s.k - 1 - (vp - 1) / 2;
+            NFc = 2 + s.mn;
+        } else if (vp >= 2 * s.k + 3) {
+            NFc = 2;
+        }
+    }
+    auto gen_of = [&](uint32_t x) -> uint32_t {
+        if (cmode == 0 || x < 2) return x;
+        uint32_t u = x - 2;
+        const uint32_t hm = s.mn >> 1;
+        const bool isH = u >= hm;
+        if (isH) u -= hm;
+        const uint32_t bitv = ((cmode == 1) != isH) ? 1u : 0u;   // L: G_j with the bit set, H_j with it clear; R: the rest
+        const uint32_t j = ((u >> cbit) << (cbit + 1)) | (bitv << cbit) | (u & ((1u << cbit) - 1u));
+        return 2 + (isH ? s.mn : 0u) + j;
+    };
     // Every lane takes G whole generators (f0, f0 + stride, ...).  The NF mod stride generators that are left
     // (g and h at n=64, m=16: 2050 = 16 * 128 + 2) are not given to two lanes as a 17th generator -- their waves
     // would run 6 % longer than the rest -- but spread window by window over all lanes in E extra steps.
-    const bool spread = s.NF >= stride;
-    const uint32_t G = spread ? s.NF / stride : (first < s.NF ? 1u : 0u);
+    const bool spread = NFc >= stride;
+    const uint32_t G = spread ? NFc / stride : (first < NFc ? 1u : 0u);
     const uint32_t T = G * s.W;                                    // whole-generator steps, the same for every lane
-    const uint32_t LW = spread ? (s.NF - G * stride) * s.W : 0u;   // left-over (generator, window) entries of the proof
+    const uint32_t LW = spread ? (NFc - G * stride) * s.W : 0u;    // left-over (generator, window) entries of the proof
     const uint32_t TT = T + (LW + stride - 1) / stride;            // + extra steps
     Xyzz<C> acc = xyzz_inf<C>();  // the running sum only ever receives affine points: 8M + 2S per addition
 
     auto dma_scalar = [&](uint32_t g) {
-        const uint32_t f = f0 + g * stride;
-        const uint32_t* src = f < s.NF ? sc + (size_t)fixed_term_index(s, f) * 8 : sc;
+        const uint32_t x = f0 + g * stride;
+        const uint32_t* src = x < NFc ? sc + (size_t)fixed_term_index(s, gen_of(x)) * 8 : sc;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous scalar has been read out of sbuf
         glds16(src, sbuf_addr);
         glds16(src + 4, sbuf_addr + 1024);
@@ -888,23 +921,24 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
                 take_scalar();
                 if (gi + 1 < G) dma_scalar(gi + 1);
             }
-            const uint32_t f = f0 + gi * stride;
+            const uint32_t x = f0 + gi * stride;
             // windows below the top: signed digit; top window: what is left of the value, unsigned (<= top)
             const int32_t dg = ji + 1 < s.W ? (int32_t)(w[0] & mask) - (int32_t)s.half : (int32_t)w[0];
 #pragma unroll
             for (int t = 0; t < 9; t++) w[t] = (w[t] >> s.c) | (w[t + 1] << (32 - s.c));
             w[9] >>= s.c;
-            if (f < s.NF && dg != 0) {
+            if (x < NFc && dg != 0) {
+                const uint32_t f = gen_of(x);
                 const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
                 src = table + ((size_t)f * s.per_f + (size_t)ji * s.half + (mag - 1)) * 2 * N;
                 valid = 1;
-                neg = dg < 0 ? 1u : 0u;
+                neg = (dg < 0 ? 1u : 0u) ^ (f >= neg_from ? 1u : 0u);
             }
         } else if (ti < TT) {
             const uint32_t x = (ti - T) * stride + f0;   // this lane's left-over entry, if any
             if (x < LW) {
                 const uint32_t l = x / s.W, jx = x - l * s.W;
-                const uint32_t f = G * stride + l;
+                const uint32_t f = gen_of(G * stride + l);
                 uint32_t we[10];
                 ld_words<8>(sc + (size_t)fixed_term_index(s, f) * 8, we);   // an ordinary load: once per block
                 we[8] = 0;
@@ -926,7 +960,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
                     const uint32_t mag = dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg;
                     src = table + ((size_t)f * s.per_f + (size_t)jx * s.half + (mag - 1)) * 2 * N;
                     valid = 1;
-                    neg = dg < 0 ? 1u : 0u;
+                    neg = (dg < 0 ? 1u : 0u) ^ (f >= neg_from ? 1u : 0u);
                 }
             }
         }

@@ -99,12 +99,13 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         for (size_t t = tid; t < n16; t += blockDim.x) q[t] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         // virtual proof 0: range A = alpha h + sum (bit ? G_i : -H_i)          (range/mod.rs:94-107 / :256-277)
-        const F one_ = F::one(), minus_one_ = fe_neg(one_);
+        // The -1 on H_i is stored as +1: k_fixed_msm negates the H_i table entries of this virtual proof instead
+        // (VpSel, kernels.hpp) -- one subtraction in place of the 15 additions of the full-width scalar r - 1.
+        const F one_ = F::one();
         for (uint32_t i = tid; i < mn; i += blockDim.x) {
             const uint32_t i1 = i % n, i2 = i / n;
             const uint32_t bit = (uint32_t)((values[p * m + i2] >> i1) & 1ull);
-            if (bit) pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + i) * 8, one_);
-            else pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + mn + i) * 8, minus_one_);
+            pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + (bit ? 0u : mn) + i) * 8, one_);
         }
         if (tid == 0) {
             pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.alpha));
