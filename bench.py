@@ -26,7 +26,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                    (naive MulVec) on one thread and on all cores, and a bucket-method (Pippenger) MulVec.
 The oracle is used only for that leg.  Beside `value` (never as it) the line also carries separately timed legs:
 "tamper_check" (exact verdict vector of the bench batch with K tampered proofs), "latency" (B = 1 / 16 / 256),
-"prove" (batched device prover, device-resident), "combined_check", "c3" (4096 x (64,1)), "hard_distribution",
+"prove" (batched device prover, device-resident), "serialized" (the same batch as proof containers + compressed
+commitments: decode with subgroup check + verify), "combined_check", "c3" (4096 x (64,1)), "hard_distribution",
 "other_curves".
 """
 
@@ -255,6 +256,8 @@ def main():
     ap.add_argument("--c3-steps", type=int, default=5, help="steps of the C3 leg (4096 x (64,1)) of a c2 run; 0 = skip")
     ap.add_argument("--latency-steps", type=int, default=5, help="steps per small-batch latency point (B = 1, 16, 256); 0 = skip")
     ap.add_argument("--prove-steps", type=int, default=2, help="steps of the device-resident batched prover leg; 0 = skip")
+    ap.add_argument("--serialized-steps", type=int, default=3,
+                    help="steps of the serialized-input leg (containers + compressed commitments resident in HBM); 0 = skip")
     ap.add_argument("--tampered", type=int, default=64, help="tampered proofs of the untimed verdict check after the timed region")
     ap.add_argument("--dry-run", action="store_true", help="launcher/collective rehearsal without a GPU (see dry_run)")
     args = ap.parse_args()
@@ -446,11 +449,66 @@ def main():
         # the proofs the timed prover wrote are the ones the batch was built from (bit-exact), and they verify
         got_p = d_po.cpu().numpy().view(np.uint64)
         assert np.array_equal(got_p, pts_[np.arange(Pn) % D]), "device-resident prover output differs from prove_batch"
+        # the same batch under the Fiat-Shamir transcript: every round's MulVecs wait for the previous round's hash
+        def pstep_fs(_i):
+            bv.prove_batch_device(d_pv.data_ptr(), d_pg.data_ptr(), Pn, d_po.data_ptr(), d_ps.data_ptr(), d_pV.data_ptr(),
+                                  d_pws.data_ptr(), pwsb, stream, transcript=True)
+
+        pstep_fs(0)
+        pdt_fs = timed(pstep_fs, args.prove_steps, torch, dist, coll_dev)
         prove = {"value": world * Pn * args.prove_steps / pdt, "unit": "proofs/s", "batch": Pn, "steps": args.prove_steps,
                  "ms_per_step": pdt / args.prove_steps * 1e3,
+                 "transcript_mode": {"value": world * Pn * args.prove_steps / pdt_fs, "unit": "proofs/s",
+                                     "ms_per_step": pdt_fs / args.prove_steps * 1e3,
+                                     "note": "challenges from the SHA-256 transcript on the device, round by round "
+                                             "(engine mode; the reference hard-codes its challenges)"},
                  "note": "RangeProof::prove + the m commitments per proof, inputs and outputs resident in HBM; "
                          "bit-identical to the single-proof path (tests/test_gpu_protocol.py)"}
         del d_pws, d_po, d_ps, d_pV
+
+    # ---- secondary, separately timed: the same batch arriving SERIALIZED (the proof container + compressed
+    # commitments, resident in HBM): header / encoding / subgroup / canonicity checks and decompression on the device,
+    # then the same verification pass -- what a service that takes proofs off the wire runs per batch
+    serialized = None
+    if args.serialized_steps > 0:
+        npp = pts_.shape[1]
+        blobs = B.encode_proofs(a, n, m, pts_, scs[:D] if D < Bsz else scs)
+        comm = B.compress_points(a, V_.reshape(-1, a.PW)).reshape(D, m, -1)
+        if D < Bsz:
+            blobs, comm = blobs[np.arange(Bsz) % D], comm[np.arange(Bsz) % D]
+        d_bl = torch.from_numpy(np.ascontiguousarray(blobs)).to(dev)
+        d_cm = torch.from_numpy(np.ascontiguousarray(comm)).to(dev)
+        swsb = bv.serialized_workspace_bytes(Bsz)
+        d_sws = torch.empty(swsb, dtype=torch.uint8, device=dev)
+        d_sok = torch.full((Bsz,), 7, dtype=torch.int32, device=dev)
+
+        def sstep(_i):
+            bv.verify_serialized_device(d_bl.data_ptr(), d_cm.data_ptr(), Bsz, d_sok.data_ptr(), d_sws.data_ptr(), swsb,
+                                        stream)
+
+        sstep(0)
+        sdt = timed(sstep, args.serialized_steps, torch, dist, coll_dev)
+        assert int(d_sok.cpu().numpy().sum()) == 0, "a valid serialized proof failed to verify"
+        in_bytes = blobs.shape[1] + m * comm.shape[2]
+        # PCIe-inclusive: the same call preceded by the host-to-device copy of the bytes (pinned host memory)
+        h_bl, h_cm = torch.from_numpy(np.ascontiguousarray(blobs)).pin_memory(), torch.from_numpy(np.ascontiguousarray(comm)).pin_memory()
+
+        def sstep_h(_i):
+            d_bl.copy_(h_bl, non_blocking=True)
+            d_cm.copy_(h_cm, non_blocking=True)
+            sstep(_i)
+
+        sstep_h(0)
+        sdt_h = timed(sstep_h, args.serialized_steps, torch, dist, coll_dev)
+        serialized = {"value": world * Bsz * args.serialized_steps / sdt, "unit": "verifies/s", "steps": args.serialized_steps,
+                      "ms_per_step": sdt / args.serialized_steps * 1e3, "bytes_per_proof": int(in_bytes),
+                      "points_decoded_per_proof": int(npp + m),
+                      "from_pinned_host": {"value": world * Bsz * args.serialized_steps / sdt_h, "unit": "verifies/s",
+                                           "ms_per_step": sdt_h / args.serialized_steps * 1e3},
+                      "note": "input = the versioned proof container + compressed commitments (include/bpp_amd.h), already in "
+                              "HBM; decode (square root, G1 subgroup check, canonicity) + verification; `from_pinned_host` "
+                              "adds the PCIe copy of those bytes.  Engine data format: the reference never serializes"}
+        del d_sws, d_bl, d_cm
 
     # ---- secondary, separately timed: the combined batch check (engine mode, not the reference's per-proof
     # semantics; see include/bpp_amd.h).  One weighted MulVec per rank, partials exchanged once per step.
@@ -705,6 +763,7 @@ def main():
             "tamper_check": tamper,
             "latency": latency,
             "prove": prove,
+            "serialized": serialized,
             "combined_check": comb,
             "c3": c3,
             "hard_distribution": hard,

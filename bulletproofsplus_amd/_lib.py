@@ -36,7 +36,8 @@ EXPORTS = [
     "bpp_verifier_derive_challenges", "bpp_range_prove_batch_fs", "bpp_range_prove_batch_fs_device",
     "bpp_point_compressed_bytes", "bpp_points_compress", "bpp_points_decompress", "bpp_points_decompress_device",
     "bpp_range_verify_batch_compressed", "bpp_proof_bytes", "bpp_proofs_encode", "bpp_proofs_decode",
-    "bpp_range_verify_batch_serialized",
+    "bpp_range_verify_batch_serialized", "bpp_verifier_serialized_workspace_bytes",
+    "bpp_range_verify_batch_serialized_device",
 ]
 
 
@@ -113,6 +114,9 @@ def lib():
         L.bpp_proofs_encode.argtypes = [vp, sz, sz, vp, vp, sz, vp]
         L.bpp_proofs_decode.argtypes = [vp, sz, sz, vp, sz, vp, vp, vp]
         L.bpp_range_verify_batch_serialized.argtypes = [vp, vp, vp, sz, i32, vp]
+        L.bpp_verifier_serialized_workspace_bytes.argtypes = [vp, sz]
+        L.bpp_verifier_serialized_workspace_bytes.restype = sz
+        L.bpp_range_verify_batch_serialized_device.argtypes = [vp, vp, vp, sz, i32, vp, vp, sz, vp]
         L.bpp_debug_field_op.argtypes = [vp, i32, i32, vp, vp, sz, vp]
         L.bpp_debug_point_op.argtypes = [vp, i32, vp, vp, sz, vp]
         _lib = L

@@ -487,6 +487,18 @@ class BatchVerifier:
               "bpp_range_verify_batch_serialized")
         return ok
 
+    def serialized_workspace_bytes(self, count: int) -> int:
+        return _lib.lib().bpp_verifier_serialized_workspace_bytes(self.handle, count)
+
+    def verify_serialized_device(self, d_proofs: int, d_commitments: int, count: int, d_ok: int, d_workspace: int,
+                                 workspace_bytes: int, stream: int = 0, transcript: bool = False):
+        """verify_serialized with every buffer in HBM (raw device pointers), asynchronous on `stream`: containers and
+        compressed commitments in, per-proof status words (0 / 1 / 2) out"""
+        check(_lib.lib().bpp_range_verify_batch_serialized_device(self.handle, d_proofs, d_commitments, count,
+                                                                  1 if transcript else 0, d_ok, d_workspace,
+                                                                  workspace_bytes, stream or None),
+              "bpp_range_verify_batch_serialized_device")
+
     def run_device(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,
                    stream: int = 0, d_challenges: int = 0, d_out_scalars: int = 0, d_out_result: int = 0):
         check(_lib.lib().bpp_verifier_run(self.handle, d_points, d_scalars, count, d_challenges or None, d_ok,

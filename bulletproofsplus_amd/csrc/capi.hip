@@ -516,58 +516,51 @@ extern "C" int bpp_proofs_decode(bpp_ctx* ctx, size_t n, size_t m, const uint8_t
     return BPP_OK;
 }
 
+extern "C" size_t bpp_verifier_serialized_workspace_bytes(const bpp_verifier* v, size_t count) {
+    if (!v) return 0;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::ser_layout(v->s, count).total;
+        return 0;
+    });
+    return r;
+}
+
+extern "C" int bpp_range_verify_batch_serialized_device(bpp_verifier* v, const void* d_proofs, const void* d_commitments,
+                                                        size_t count, int transcript, uint32_t* d_ok, void* d_workspace,
+                                                        size_t workspace_bytes, void* stream) {
+    if (!v || !d_proofs || !d_commitments || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
+    if (count == 0) return BPP_OK;
+    if (count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count too large for one launch");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::run_serialized(v, static_cast<const uint8_t*>(d_proofs),
+                                                        static_cast<const uint8_t*>(d_commitments), count, transcript != 0,
+                                                        d_ok, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    });
+}
+
+// host buffers in, host verdicts out: the device path above between two copies
 extern "C" int bpp_range_verify_batch_serialized(bpp_verifier* v, const uint8_t* proofs, const uint8_t* commitments,
                                                  size_t count, int transcript, uint32_t* out_ok) {
     if (!v || !proofs || !commitments || !out_ok) return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
     HIPCHK(hipSetDevice(v->ctx.device));
     const VerifyShape& s = v->s;
+    const size_t pb = bpp_proof_bytes(v->ctx.curve, s.n, s.m);
     const size_t cb = bpp_point_compressed_bytes(v->ctx.curve);
-    const size_t pw = (size_t)bpp_point_words(v->ctx.curve) * 8;
-    const size_t npp = 3 + 2 * (size_t)s.k;
-    DevBuf dproof;
-    std::vector<uint64_t> sc;
-    std::vector<uint32_t> st;
-    int rc = proofs_decode_common(&v->ctx, s.n, s.m, proofs, count, dproof, sc, st);
-    if (rc) return rc;
-    // the commitments, decoded with the same checks
-    DevBuf dcb, dck, dV, drec, dsc, dok, dws, dch;
-    HIPCHK(dcb.alloc(count * s.m * cb));
-    HIPCHK(dck.alloc(count * s.m * 4));
-    HIPCHK(dV.alloc(count * s.m * pw));
-    HIPCHK(hipMemcpy(dcb.p, commitments, count * s.m * cb, hipMemcpyHostToDevice));
-    rc = dispatch(v->ctx.curve, [&](auto cv) -> int {
-        return CodecImpl<decltype(cv)>::decompress_device(static_cast<const uint8_t*>(dcb.p), count * s.m,
-                                                          static_cast<uint64_t*>(dV.p), dck.u32(), nullptr, true);
-    });
-    if (rc) return rc;
-    std::vector<uint32_t> badV(count * s.m);
-    HIPCHK(hipMemcpy(badV.data(), dck.p, badV.size() * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < badV.size(); i++)
-        if (badV[i]) st[i / s.m] = BPP_FORMAT_ERROR;
-    // records [A, wip.A, wip.B, L.., R.., V..] per proof
-    HIPCHK(drec.alloc(count * s.NV * pw));
-    HIPCHK(hipMemcpy2D(drec.p, s.NV * pw, dproof.p, npp * pw, npp * pw, count, hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy2D(static_cast<uint8_t*>(drec.p) + npp * pw, s.NV * pw, dV.p, s.m * pw, s.m * pw, count,
-                       hipMemcpyDeviceToDevice));
-    HIPCHK(dsc.alloc(count * 96));
-    HIPCHK(hipMemcpy(dsc.p, sc.data(), count * 96, hipMemcpyHostToDevice));
+    if (pb == 0 || s.n > 255 || s.m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255)");
+    DevBuf dpr, dcm, dok, dws;
+    const size_t wsb = bpp_verifier_serialized_workspace_bytes(v, count);
+    HIPCHK(dpr.alloc(count * pb));
+    HIPCHK(dcm.alloc(count * s.m * cb));
     HIPCHK(dok.alloc(count * 4));
-    const size_t wsb = bpp_verifier_workspace_bytes(v, count);
     HIPCHK(dws.alloc(wsb));
-    const uint64_t* d_ch = nullptr;
-    if (transcript) {
-        HIPCHK(dch.alloc(count * (size_t)(3 + s.k) * 32));
-        rc = bpp_verifier_derive_challenges(v, static_cast<const uint64_t*>(drec.p), count, static_cast<uint64_t*>(dch.p), nullptr);
-        if (rc) return rc;
-        d_ch = static_cast<const uint64_t*>(dch.p);
-    }
-    rc = bpp_verifier_run(v, static_cast<const uint64_t*>(drec.p), static_cast<const uint64_t*>(dsc.p), count, d_ch, dok.u32(),
-                          dws.p, wsb, nullptr, nullptr, nullptr);
+    HIPCHK(hipMemcpy(dpr.p, proofs, count * pb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dcm.p, commitments, count * s.m * cb, hipMemcpyHostToDevice));
+    int rc = bpp_range_verify_batch_serialized_device(v, dpr.p, dcm.p, count, transcript, dok.u32(), dws.p, wsb, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
-    for (size_t p = 0; p < count; p++)
-        if (st[p]) out_ok[p] = BPP_FORMAT_ERROR;   // ProofError::FormatError takes precedence over the MulVec verdict
     return BPP_OK;
 }
 

@@ -98,23 +98,18 @@ __global__ void __launch_bounds__(128) k_points_compress(const uint32_t* __restr
     }
 }
 
-// one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (bad flags, x >= p, x not on the curve,
-// not a ristretto255 encoding; with check_subgroup also: outside the prime-order subgroup)
+// compressed bytes -> wire point at w (2N + 2 words).  false: malformed (bad flags, x >= p, x not on the curve, not a
+// ristretto255 encoding; with check_subgroup also: outside the prime-order subgroup) -- w then holds infinity, so that
+// a consumer that ignores the verdict still sees a valid wire point.
 template <class C>
-__global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
-                                                          uint32_t* __restrict__ ok, size_t n, uint32_t check_subgroup) {
+__device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __restrict__ w, bool check_subgroup) {
     using P = typename C::Fp;
     using F = Fe<P>;
     constexpr int N = P::N;
-    constexpr int CB = compressed_bytes<C>();
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t* s = in + i * CB;
-    uint32_t* w = wire + i * (2 * N + 2);
     auto fail_point = [&]() {
         for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
-        w[2 * N] = 1;   // infinity, so that a consumer that ignores ok[] still sees a valid wire point
-        ok[i] = 1;
+        w[2 * N] = 1;
+        return false;
     };
     if constexpr (C::ID == 2) {
         Aff<C> a;
@@ -123,77 +118,137 @@ __global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restr
         fe_to_canonical(a.y, w + N);
         w[2 * N] = 0;
         w[2 * N + 1] = 0;
-        ok[i] = 0;
+        return true;
     } else {
-    uint32_t x[N];
-    for (int t = 0; t < N; t++) x[t] = 0;
-    bool inf = false, want_flag = false;
-    if (C::ID == 0) {
-        const uint8_t f = s[0];
-        if (!(f & 0x80)) return fail_point();   // uncompressed form is not accepted here
-        inf = (f & 0x40) != 0;
-        want_flag = (f & 0x20) != 0;
-        for (int b = 0; b < 48; b++) {
-            const int k = 47 - b;
-            const uint32_t v = b == 0 ? (uint32_t)(s[0] & 0x1f) : (uint32_t)s[b];
-            x[k >> 2] |= v << (8 * (k & 3));
-        }
-        if (inf) {
-            bool zero = !want_flag;
-            for (int t = 0; t < N; t++) zero = zero && x[t] == 0;
-            if (!zero) return fail_point();   // infinity must be 0xc0 00 .. 00
-        }
-    } else {
-        const uint8_t f = s[0];
-        bool all_zero = true;
-        for (int b = 0; b < 33; b++) all_zero = all_zero && s[b] == 0;
-        if (all_zero) {
-            inf = true;
+        uint32_t x[N];
+        for (int t = 0; t < N; t++) x[t] = 0;
+        bool inf = false, want_flag = false;
+        if (C::ID == 0) {
+            const uint8_t f = s[0];
+            if (!(f & 0x80)) return fail_point();   // uncompressed form is not accepted here
+            inf = (f & 0x40) != 0;
+            want_flag = (f & 0x20) != 0;
+            for (int b = 0; b < 48; b++) {
+                const int k = 47 - b;
+                const uint32_t v = b == 0 ? (uint32_t)(s[0] & 0x1f) : (uint32_t)s[b];
+                x[k >> 2] |= v << (8 * (k & 3));
+            }
+            if (inf) {
+                bool zero = !want_flag;
+                for (int t = 0; t < N; t++) zero = zero && x[t] == 0;
+                if (!zero) return fail_point();   // infinity must be 0xc0 00 .. 00
+            }
         } else {
-            if (f != 0x02 && f != 0x03) return fail_point();
-            want_flag = f == 0x03;   // y odd
-            for (int b = 0; b < 32; b++) {
-                const int k = 31 - b;
-                x[k >> 2] |= (uint32_t)s[1 + b] << (8 * (k & 3));
+            const uint8_t f = s[0];
+            bool all_zero = true;
+            for (int b = 0; b < 33; b++) all_zero = all_zero && s[b] == 0;
+            if (all_zero) {
+                inf = true;
+            } else {
+                if (f != 0x02 && f != 0x03) return fail_point();
+                want_flag = f == 0x03;   // y odd
+                for (int b = 0; b < 32; b++) {
+                    const int k = 31 - b;
+                    x[k >> 2] |= (uint32_t)s[1 + b] << (8 * (k & 3));
+                }
             }
         }
-    }
-    if (inf) {
-        for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
-        w[2 * N] = 1;
-        ok[i] = 0;
-        return;
-    }
-    if (!words_lt_mod<P>(x)) return fail_point();
-    const F xm = fe_from_canonical<P>(x);
-    F b;
+        if (inf) {
+            for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
+            w[2 * N] = 1;
+            return true;
+        }
+        if (!words_lt_mod<P>(x)) return fail_point();
+        const F xm = fe_from_canonical<P>(x);
+        F b;
 #pragma unroll
-    for (int t = 0; t < P::NL; t++) b.l[t] = C::K::B[t];
-    const F rhs = fe_add(fe_mul(fe_sqr(xm), xm), b);
-    F y = fe_sqrt_3mod4(rhs);
-    if (fe_sqr(y) != rhs) return fail_point();   // x^3 + b is not a square: no such point
-    uint32_t yw[N];
-    fe_to_canonical(y, yw);
-    const bool flag = C::ID == 0 ? words_gt_half<P>(yw) : (yw[0] & 1u) != 0;
-    if (flag != want_flag) {
-        y = fe_neg(y);
+        for (int t = 0; t < P::NL; t++) b.l[t] = C::K::B[t];
+        const F rhs = fe_add(fe_mul(fe_sqr(xm), xm), b);
+        F y = fe_sqrt_3mod4(rhs);
+        if (fe_sqr(y) != rhs) return fail_point();   // x^3 + b is not a square: no such point
+        uint32_t yw[N];
         fe_to_canonical(y, yw);
+        const bool flag = C::ID == 0 ? words_gt_half<P>(yw) : (yw[0] & 1u) != 0;
+        if (flag != want_flag) {
+            y = fe_neg(y);
+            fe_to_canonical(y, yw);
+        }
+        if (check_subgroup) {
+            Aff<C> a;
+            a.x = xm;
+            a.y = y;
+            if (!aff_in_prime_subgroup(a)) return fail_point();
+        }
+        // y = 0 cannot carry the "larger" / "odd" flag; it does not occur on these curves (no point of order 2)
+        for (int t = 0; t < N; t++) {
+            w[t] = x[t];
+            w[N + t] = yw[t];
+        }
+        w[2 * N] = 0;
+        w[2 * N + 1] = 0;
+        return true;
     }
-    if (check_subgroup) {
-        Aff<C> a;
-        a.x = xm;
-        a.y = y;
-        if (!aff_in_prime_subgroup(a)) return fail_point();
+}
+
+// one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (see point_decompress)
+template <class C>
+__global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
+                                                          uint32_t* __restrict__ ok, size_t n, uint32_t check_subgroup) {
+    constexpr int N = C::Fp::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ok[i] = point_decompress<C>(in + i * compressed_bytes<C>(), wire + i * (2 * N + 2), check_subgroup != 0) ? 0u : 1u;
+}
+
+// ---- the proof container on the device (layout: include/bpp_amd.h "serialized proofs") ---------------------------
+constexpr uint32_t CONTAINER_HDR = 12;   // "BPP+" | version | curve | n | m | k | 3 reserved zero bytes
+template <class C>
+__host__ __device__ constexpr size_t container_bytes(uint32_t k) {
+    return CONTAINER_HDR + (size_t)(3 + 2 * k) * compressed_bytes<C>() + 96;
+}
+
+// One lane per point of every proof's verification record [A, wip.A, wip.B, L.., R.., V_0..V_{m-1}]: the 3 + 2k points
+// of the container and the m commitments, decompressed WITH the subgroup check straight into the layout
+// bpp_verifier_run reads.  The lane of a proof's first point also checks the header and the canonicity of r', s',
+// delta' and copies them out.  status[p] (zeroed by the caller) becomes non-zero when anything of proof p is rejected.
+template <class C>
+__global__ void __launch_bounds__(64) k_container_decode(VerifyShape s, const uint8_t* __restrict__ proofs,
+                                                         const uint8_t* __restrict__ commitments,
+                                                         uint32_t* __restrict__ records, uint32_t* __restrict__ scalars,
+                                                         uint32_t* __restrict__ status, size_t count) {
+    constexpr int N = C::Fp::N;
+    constexpr int CB = compressed_bytes<C>();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * s.NV) return;
+    const size_t p = i / s.NV;
+    const uint32_t t = (uint32_t)(i - p * s.NV);
+    const uint32_t npp = 3 + 2 * s.k;
+    const uint8_t* rec = proofs + p * container_bytes<C>(s.k);
+    const uint8_t* src = t < npp ? rec + CONTAINER_HDR + (size_t)t * CB : commitments + (p * s.m + (t - npp)) * CB;
+    bool good = point_decompress<C>(src, records + i * (2 * N + 2), true);
+    if (t == 0) {
+        const uint8_t hdr[CONTAINER_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)C::ID, (uint8_t)s.n, (uint8_t)s.m, (uint8_t)s.k, 0, 0, 0};
+        for (uint32_t b = 0; b < CONTAINER_HDR; b++) good = good && rec[b] == hdr[b];
+        const uint8_t* sc = rec + CONTAINER_HDR + (size_t)npp * CB;
+        for (int e = 0; e < 3; e++) {
+            uint32_t w[8];
+            for (int q = 0; q < 8; q++)
+                w[q] = (uint32_t)sc[32 * e + 4 * q] | ((uint32_t)sc[32 * e + 4 * q + 1] << 8) |
+                       ((uint32_t)sc[32 * e + 4 * q + 2] << 16) | ((uint32_t)sc[32 * e + 4 * q + 3] << 24);
+            good = good && words_lt_mod<typename C::Fr>(w);   // one encoding per scalar
+            for (int q = 0; q < 8; q++) scalars[(p * 3 + e) * 8 + q] = w[q];
+        }
     }
-    // y = 0 cannot carry the "larger" / "odd" flag; it does not occur on these curves (no point of order 2)
-    for (int t = 0; t < N; t++) {
-        w[t] = x[t];
-        w[N + t] = yw[t];
-    }
-    w[2 * N] = 0;
-    w[2 * N + 1] = 0;
-    ok[i] = 0;
-    }   // Weierstrass encodings
+    if (!good) atomicOr(status + p, 1u);
+}
+
+// ok[p] = BPP_FORMAT_ERROR where the decoder rejected proof p: ProofError::FormatError takes precedence over the
+// MulVec verdict
+template <class C>
+__global__ void __launch_bounds__(256) k_container_status(const uint32_t* __restrict__ status, uint32_t* __restrict__ ok,
+                                                          size_t count) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < count && status[p]) ok[p] = BPP_FORMAT_ERROR;
 }
 
 template <class C>

@@ -1,6 +1,7 @@
 // impl_verify.hpp -- the batch verifier (bpp_verifier_*): window tables in HBM + one pass of the hot path
 // over a device-resident batch.  One instantiation per curve (tu_verify_*.hip).
 #pragma once
+#include "codec.hpp"
 #include "combined.hpp"
 #include "host_util.hpp"
 #include "pippenger.hpp"
@@ -114,6 +115,33 @@ struct VerifyImpl {
 
     static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
                                  hipStream_t st);
+
+    // ---- RangeProof::verify over SERIALIZED proofs resident in HBM (codec.hpp: the container) ---------------
+    // workspace = decoded records | scalars | decoder status | challenges (transcript mode) | run()'s workspace
+    struct SerLayout {
+        size_t records, scalars, status, challenges, run, total;
+    };
+    static SerLayout ser_layout(const VerifyShape& s, size_t count) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        SerLayout w;
+        size_t o = 0;
+        w.records = o;
+        o += al(count * s.NV * WW * 4);
+        w.scalars = o;
+        o += al(count * 96);
+        w.status = o;
+        o += al(count * 4);
+        w.challenges = o;
+        o += al(count * (size_t)(3 + s.k) * 32);
+        w.run = o;
+        o += ws_layout(s, count).total;
+        w.total = o;
+        return w;
+    }
+    // d_proofs: count x container_bytes ; d_commitments: count x m compressed points ; d_ok: 0 Ok / 1 VerificationError /
+    // 2 FormatError per proof.  Everything on `st`, no host synchronisation.
+    static int run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
+                              bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes, hipStream_t st);
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
@@ -366,6 +394,35 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_last, last, w_vp, 1u, w_bad, d_ok,
                        reinterpret_cast<uint32_t*>(d_out_result), count);
     HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
+    HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
+                                  bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
+                                  hipStream_t st) {
+    const VerifyShape& s = v->s;
+    if (s.n > 255 || s.m > 255) return fail(BPP_E_ARG, "the container holds n, m <= 255");
+    const SerLayout L = ser_layout(s, count);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    uint32_t* w_rec = reinterpret_cast<uint32_t*>(ws + L.records);
+    uint32_t* w_sc = reinterpret_cast<uint32_t*>(ws + L.scalars);
+    uint32_t* w_st = reinterpret_cast<uint32_t*>(ws + L.status);
+    uint64_t* w_ch = reinterpret_cast<uint64_t*>(ws + L.challenges);
+    HIPCHK(hipMemsetAsync(w_st, 0, count * 4, st));
+    hipLaunchKernelGGL(k_container_decode<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, s, d_proofs, d_commitments,
+                       w_rec, w_sc, w_st, count);
+    HIPCHK(hipGetLastError());
+    if (transcript) {
+        int rc = derive_challenges(v, reinterpret_cast<const uint64_t*>(w_rec), count, w_ch, st);
+        if (rc) return rc;
+    }
+    int rc = run(v, reinterpret_cast<const uint64_t*>(w_rec), reinterpret_cast<const uint64_t*>(w_sc), count,
+                 transcript ? w_ch : nullptr, d_ok, ws + L.run, workspace_bytes - L.run, nullptr, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_container_status<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, w_st, d_ok, count);
     HIPCHK(hipGetLastError());
     return BPP_OK;
 }

@@ -282,6 +282,14 @@ int bpp_proofs_decode(bpp_ctx *ctx, size_t n, size_t m, const uint8_t *in, size_
  * out_ok[p] = 0 Ok / 1 VerificationError / 2 FormatError. */
 int bpp_range_verify_batch_serialized(bpp_verifier *v, const uint8_t *proofs, const uint8_t *commitments, size_t count,
                                       int transcript, uint32_t *out_ok);
+/* The same with every buffer in HBM, asynchronous on `stream`, no host synchronisation: what a service that receives
+ * proofs off the wire calls after one copy.  One kernel decodes the containers and the commitments (header, point
+ * encodings with the subgroup check, scalar canonicity) straight into bpp_verifier_run's record layout inside the
+ * workspace; d_ok[p] = 0 / 1 / 2 as above.  d_workspace: bpp_verifier_serialized_workspace_bytes(v, count) bytes. */
+size_t bpp_verifier_serialized_workspace_bytes(const bpp_verifier *v, size_t count);
+int bpp_range_verify_batch_serialized_device(bpp_verifier *v, const void *d_proofs, const void *d_commitments, size_t count,
+                                             int transcript, uint32_t *d_ok, void *d_workspace, size_t workspace_bytes,
+                                             void *stream);
 
 /* name of the kernel that dominates bpp_verifier_run (for profilers) and its launch geometry */
 const char *bpp_verifier_dominant_kernel(void);

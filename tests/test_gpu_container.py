@@ -182,3 +182,54 @@ def test_hashed_generators(cname):
         assert bv.verify_serialized(blobs, comm, transcript=fs).tolist() == [0, 0]
         assert bv.verify_serialized(blobs, comm, transcript=not fs).tolist() == [1, 1]
     bv.close()
+
+
+@pytest.mark.parametrize("cname", ["bls12_381", "secp256k1", "ed25519"])
+def test_serialized_device_path(cname):
+    """bpp_range_verify_batch_serialized_device: containers and compressed commitments resident in HBM -> status words,
+    no host round trip.  70 proofs (a ragged last wave of the decoder), rejections of every kind at known indices, both
+    challenge modes; the host-pointer entry point must give the same vector."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    c = P.CURVES[cname]
+    a = B.Arith.init(cname)
+    n, m, cnt = 8, 2, 70
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=5)
+    vals = [[(7 * i + 1) % 256, (3 * i) % 256] for i in range(cnt)]
+    gams = [[i + 1, 2 * i + 5] for i in range(cnt)]
+    dev = torch.device("cuda:0")
+    for fs in (False, True):
+        pts, scs, V = bv.prove_batch(vals, gams, transcript=fs)
+        blobs = B.encode_proofs(a, n, m, pts, scs)
+        comm = B.compress_points(a, V.reshape(-1, a.PW)).reshape(cnt, m, -1)
+        exp = [0] * cnt
+        blobs[3, 0] = ord("X")                   # magic
+        exp[3] = 2
+        blobs[17, 9] = 1                         # reserved byte
+        exp[17] = 2
+        blobs[40, -96:-64] = np.frombuffer(c["r"].to_bytes(32, "little"), dtype=np.uint8)   # r' = group order
+        exp[40] = 2
+        blobs[41, -96] ^= 1                      # r' off by one: parses, fails the MulVec
+        exp[41] = 1
+        blobs[69, 12 + B.compressed_bytes(a)] ^= 0x55 if cname != "secp256k1" else 0x04   # wip.A: garbage encoding
+        comm[5, 1], comm[6, 1] = comm[6, 1].copy(), comm[5, 1].copy()   # valid points, wrong proofs
+        exp[5] = exp[6] = 1
+        d_pr = torch.from_numpy(blobs).to(dev)
+        d_cm = torch.from_numpy(comm.copy()).to(dev)
+        d_ok = torch.full((cnt,), 9, dtype=torch.int32, device=dev)
+        wsb = bv.serialized_workspace_bytes(cnt)
+        d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        bv.verify_serialized_device(d_pr.data_ptr(), d_cm.data_ptr(), cnt, d_ok.data_ptr(), d_ws.data_ptr(), wsb,
+                                    transcript=fs)
+        torch.cuda.synchronize()
+        got = d_ok.cpu().numpy().tolist()
+        host = bv.verify_serialized(blobs, comm, transcript=fs).tolist()
+        assert got == host
+        # index 69: a flipped byte of an encoding is rejected by the decoder or, if it happens to decode, by the MulVec
+        assert got[69] in (1, 2)
+        exp[69] = got[69]
+        assert got == exp
+        with pytest.raises(B.BppError):
+            bv.verify_serialized_device(d_pr.data_ptr(), d_cm.data_ptr(), cnt, d_ok.data_ptr(), d_ws.data_ptr(), wsb - 1)
+    bv.close()
