@@ -195,7 +195,7 @@ struct VerifyImpl {
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
     // and nothing synchronises.  The batch is processed in chunks that reuse one workspace.
     struct ProveLayout {
-        size_t a, b, cG, cH, pwy, con, vps, part, vout, trst, ch, total;
+        size_t a, b, cG, cH, pwy, con, vps, part, part1, part2, vout, trst, ch, total;
         size_t chunk;
         unsigned per;
     };
@@ -228,7 +228,11 @@ struct VerifyImpl {
         w.vps = o;
         o += al(nv_total * (size_t)s.N * 32);
         w.part = o;
-        o += al(nv_total * w.per * JW * 4);
+        o += al(nv_total * w.per * FIXED_BLOCK * JW * 4);                                  // one partial per thread
+        w.part1 = o;
+        o += al(nv_total * w.per * (FIXED_BLOCK / FOLD_GROUP) * JW * 4);                   // folded 8 to 1
+        w.part2 = o;
+        o += al(nv_total * w.per * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2) * JW * 4);     // then 4 to 1
         w.vout = o;
         o += al(w.chunk * (size_t)s.m * WW * 4);   // the commitments of a chunk when the caller does not want them
         w.trst = o;
@@ -537,10 +541,16 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
             const size_t nv = cnt * sel.cnt;
             // never more blocks per virtual proof than the workspace was sized for
             const unsigned per = std::min(L.per, blocks_per_proof(s, nv));
-            hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
+            hipLaunchKernelGGL((k_fixed_msm<C, 2>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
                                W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
                                (uint32_t*)nullptr, (size_t)0, 0u, sel);
-            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv, 64)), dim3(64), 0, st, s, sel, W(L.part), per, o_pts, o_V, nv);
+            // per-thread partials -> 16 -> 4 per block with every lane busy (as the verifier does); k_pb_collect adds
+            // the 4 * per that are left of each MulVec
+            const size_t f1 = nv * per * (FIXED_BLOCK / FOLD_GROUP), f2 = f1 / FOLD_GROUP2;
+            hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(f1, 64)), dim3(64), 0, st, W(L.part), FOLD_GROUP, W(L.part1), f1);
+            hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(f2, 64)), dim3(64), 0, st, W(L.part1), FOLD_GROUP2, W(L.part2), f2);
+            hipLaunchKernelGGL(k_pb_collect<C>, dim3(cdiv(nv, 64)), dim3(64), 0, st, s, sel, W(L.part2),
+                               per * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2), o_pts, o_V, nv);
         };
         if (!fs) {
             hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, 0u, vals, gams,

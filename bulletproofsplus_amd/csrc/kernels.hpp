@@ -799,9 +799,10 @@ struct VpSel {
 // Fixed-generator part: for proof b, sum_f scalar_f * F_f through the window tables.
 // scalar + bias -> W windows -> signed digits in [-half, half) (top window: unsigned) -> one table gather and
 // one mixed addition per (generator, window).  No doublings, no buckets, no scatter: the 288 GB of HBM pay for
-// that.  partials: ROLE 0: [count][per][blockDim.x] jacobians (one per thread, summed by k_partials_fold);
-// ROLE 1: [count][per] (block sums).  ROLE also separates the launches in profiles: 0 = the batch verifier's
-// hot path, 1 = prover / combined check.
+// that.  partials: ROLE 0, 2: [count][per][blockDim.x] jacobians (one per thread, summed by k_partials_fold);
+// ROLE 1: [count][per] (block sums: the combined check's single MulVec, whose handful of blocks is summed by one
+// lane).  ROLE also separates the launches in profiles: 0 = the batch verifier's hot path, 1 = combined check,
+// 2 = batched prover.
 //
 // Gathers: a wave spends ~20 us on one mixed addition (7 300 instructions at two waves per SIMD), far longer than
 // a random 96-byte HBM read, so latency is not the issue -- registers are: 24 VGPRs of landing space for the
@@ -1002,7 +1003,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
         if (valid) xyzz_madd_lazy(acc, cur, neg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs have landed: LDS may be reused
-    if (ROLE == 0) {
+    if (ROLE != 1) {
         // one partial per THREAD: a tree reduction here would run 7 jacobian additions with most lanes idle
         // (~4.5 % of the block's time); k_partials_fold sums them with every lane busy
         jac_stg<C>(partials + ((size_t)bid * blockDim.x + threadIdx.x) * JW, xyzz_to_jac(acc));
