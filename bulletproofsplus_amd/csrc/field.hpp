@@ -21,6 +21,8 @@
 // product, plus one shift + one mask per column.  No MFMA: there is no carry chain in the matrix pipe.
 #pragma once
 #include <stdint.h>
+#include <type_traits>
+
 #include "constants_gen.h"
 
 #if defined(__HIPCC__)
@@ -307,11 +309,77 @@ __device__ __forceinline__ void chain_barrier_m(uint64_t& acc, uint32_t* m) {
         asm volatile("" : "+v"(acc), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]),
                           "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), "+v"(m[12]));
 }
+// ... and over both accumulators and ALL limbs of one (or two) operands of the plain products.  LLVM's reassociation
+// orders the terms of a column sum by how late they are defined and seeds the chain with the EARLIEST: the operands
+// of a * b are old values, so left alone the products are summed on their own from zero and the carry joins with a
+// 64-bit add.  After this statement the operand limbs are "younger" than the carries, and every column is one chain
+// of multiply-adds that starts from its carry.  No instruction is emitted; the operand must be a copy the caller no
+// longer needs in its old form (a value still live elsewhere would cost a register move per limb).
+#define BPP_L9(x) "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8])
+#define BPP_L13(x) BPP_L9(x), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12])
+// one statement for everything (two statements in a row cost a wait state each: the hazard recogniser assumes the
+// worst of an inline asm's outputs): both accumulators, the CNT reduction multipliers the next column reads, and the
+// operand limbs given as the variadic part
+#define BPP_PIN_CASES(...)                                                                                                   \
+    if constexpr (CNT == 0) asm volatile("" : "+v"(accB), "+v"(accA), __VA_ARGS__);                                         \
+    if constexpr (CNT == 1) asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), __VA_ARGS__);                             \
+    if constexpr (CNT == 2) asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), __VA_ARGS__);                 \
+    if constexpr (CNT == 3) asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), __VA_ARGS__);     \
+    if constexpr (CNT == 4)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), __VA_ARGS__);             \
+    if constexpr (CNT == 5)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), __VA_ARGS__); \
+    if constexpr (CNT == 6)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          __VA_ARGS__);                                                                                      \
+    if constexpr (CNT == 7)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), __VA_ARGS__);                                                                          \
+    if constexpr (CNT == 8)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), __VA_ARGS__);                                                              \
+    if constexpr (CNT == 9)                                                                                                  \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), __VA_ARGS__);                                                  \
+    if constexpr (CNT == 10)                                                                                                 \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), __VA_ARGS__);                                      \
+    if constexpr (CNT == 11)                                                                                                 \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), __VA_ARGS__);                         \
+    if constexpr (CNT == 12)                                                                                                 \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), __VA_ARGS__);            \
+    if constexpr (CNT == 13)                                                                                                 \
+        asm volatile("" : "+v"(accB), "+v"(accA), "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]),   \
+                          "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), "+v"(m[12]), __VA_ARGS__);
+template <int NL, int CNT>
+__device__ __forceinline__ void chain_barrier_ops(uint64_t& accB, uint64_t& accA, uint32_t* m, uint32_t* x) {
+    static_assert((NL == 9 || NL == 13) && CNT >= 0 && CNT <= 13, "limb counts of the fields in use");
+    if constexpr (NL == 9) {
+        BPP_PIN_CASES(BPP_L9(x))
+    } else {
+        BPP_PIN_CASES(BPP_L13(x))
+    }
+}
+template <int NL, int CNT>
+__device__ __forceinline__ void chain_barrier_ops(uint64_t& accB, uint64_t& accA, uint32_t* m, uint32_t* x, uint32_t* y) {
+    static_assert((NL == 9 || NL == 13) && CNT >= 0 && CNT <= 13, "limb counts of the fields in use");
+    if constexpr (NL == 9) {
+        BPP_PIN_CASES(BPP_L9(x), BPP_L9(y))
+    } else {
+        BPP_PIN_CASES(BPP_L13(x), BPP_L13(y))
+    }
+}
 #else
 #define BPP_CHAIN_BARRIER(acc) ((void)0)
 BPP_HD uint32_t opaque_one() { return 1u; }
 template <int CNT>
 BPP_HD void chain_barrier_m(uint64_t&, uint32_t*) {}
+template <int NL, int CNT>
+BPP_HD void chain_barrier_ops(uint64_t&, uint64_t&, uint32_t*, uint32_t*) {}
+template <int NL, int CNT>
+BPP_HD void chain_barrier_ops(uint64_t&, uint64_t&, uint32_t*, uint32_t*, uint32_t*) {}
 #endif
 
 // Montgomery reduction of a 2*NL-limb product T (limbs < 2^31): returns T * R^-1 mod p.
@@ -406,8 +474,8 @@ BPP_HD void fe_mad_k(uint64_t& acc, uint32_t a, uint32_t k) {
     acc += (uint64_t)a * k;
 }
 
-template <class P, int W, int K, class ColFn>
-BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t* m, Fe<P>& r, uint32_t one) {
+template <class P, int W, int K, class ColFn, class PinFn>
+BPP_HD void fe_fused_column(ColFn& col, PinFn& pin, uint64_t& accA, uint64_t& accB, uint32_t* m, Fe<P>& r, uint32_t one) {
     constexpr int NL = P::NL;
     constexpr int na = K <= 2 * NL - 2 ? (K < 2 * NL - 2 - K ? K : 2 * NL - 2 - K) + 1 : 0;
     constexpr int nm = K < NL ? K + 1 : 2 * NL - 1 - K;
@@ -421,7 +489,6 @@ BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t
         col(K, accA);
         const uint32_t T = (uint32_t)accA & LIMB_MASK;
         accA >>= LIMB_BITS;
-        BPP_CHAIN_BARRIER(accA);
         fe_mad(accB, T, one);
     } else {
         if constexpr (prev_split) accB += accA;
@@ -442,17 +509,17 @@ BPP_HD void fe_fused_column(ColFn& col, uint64_t& accA, uint64_t& accB, uint32_t
         // the multipliers column K + 1 reads: m[lo .. hi)
         constexpr int lo = K + 1 < NL ? 0 : K + 1 - NL + 1;
         constexpr int hi = K + 1 < NL ? K + 1 : NL;
-        chain_barrier_m<(hi > lo ? hi - lo : 0)>(accB, m + lo);
-        fe_fused_column<P, W, K + 1>(col, accA, accB, m, r, one);
+        pin(accB, accA, m + lo, std::integral_constant<int, (hi > lo ? hi - lo : 0)>{});
+        fe_fused_column<P, W, K + 1>(col, pin, accA, accB, m, r, one);
     }
 }
 
-template <class P, int W, class ColFn>
-BPP_HD Fe<P> fe_fused_reduce(ColFn&& col) {
+template <class P, int W, class ColFn, class PinFn>
+BPP_HD Fe<P> fe_fused_reduce(ColFn&& col, PinFn&& pin) {
     uint32_t m[P::NL];
     Fe<P> r;
     uint64_t accB = 0, accA = 0;   // reduction chain (and the fused columns); plain-product chain of the middle columns
-    fe_fused_column<P, W, 0>(col, accA, accB, m, r, opaque_one());
+    fe_fused_column<P, W, 0>(col, pin, accA, accB, m, r, opaque_one());
     // (T + m p) / R < T / R + p: far below 2p for every caller (T < HEADROOM / 8 p^2)  =>  accB == 0 here
     return r;
 }
@@ -461,10 +528,15 @@ BPP_HD Fe<P> fe_fused_reduce(ColFn&& col) {
 template <class P>
 BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     constexpr int NL = P::NL;
-    return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
+    uint32_t x[NL];   // a's limbs, re-"defined" at every column boundary (chain_barrier_ops): pass the operand that dies first
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) fe_mad(acc, a.l[i], b.l[k - i]);
-    });
+    for (int i = 0; i < NL; i++) x[i] = a.l[i];
+    return fe_fused_reduce<P, 1>(
+        [&](int k, uint64_t& acc) {
+#pragma unroll
+            for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) fe_mad(acc, x[i], b.l[k - i]);
+        },
+        [&](uint64_t& accB, uint64_t& accA, uint32_t* mm, auto cnt) { chain_barrier_ops<NL, decltype(cnt)::value>(accB, accA, mm, x); });
 }
 
 // (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: < p (1 + (alpha beta + gamma delta) / HEADROOM).
@@ -472,13 +544,23 @@ BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
 template <class P>
 BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe<P>& d) {
     constexpr int NL = P::NL;
-    return fe_fused_reduce<P, 2>([&](int k, uint64_t& acc) {
+    uint32_t x[NL], y[NL];
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) {
-            fe_mad(acc, a.l[i], b.l[k - i]);
-            fe_mad(acc, c.l[i], d.l[k - i]);
-        }
-    });
+    for (int i = 0; i < NL; i++) {
+        x[i] = a.l[i];
+        y[i] = c.l[i];
+    }
+    return fe_fused_reduce<P, 2>(
+        [&](int k, uint64_t& acc) {
+#pragma unroll
+            for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) {
+                fe_mad(acc, x[i], b.l[k - i]);
+                fe_mad(acc, y[i], d.l[k - i]);
+            }
+        },
+        [&](uint64_t& accB, uint64_t& accA, uint32_t* mm, auto cnt) {
+            chain_barrier_ops<NL, decltype(cnt)::value>(accB, accA, mm, x, y);
+        });
 }
 
 // Montgomery square: the NL(NL-1)/2 cross products are computed once, against a pre-doubled copy of the operand
@@ -487,15 +569,20 @@ BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe
 template <class P>
 BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
     constexpr int NL = P::NL;
-    uint32_t a2[NL];
+    uint32_t x[NL], a2[NL];
 #pragma unroll
-    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
-    return fe_fused_reduce<P, 1>([&](int k, uint64_t& acc) {
-        // pairs i < j, i + j = k
+    for (int i = 0; i < NL; i++) {
+        x[i] = a.l[i];
+        a2[i] = a.l[i] << 1;
+    }
+    return fe_fused_reduce<P, 1>(
+        [&](int k, uint64_t& acc) {
+            // pairs i < j, i + j = k
 #pragma unroll
-        for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) fe_mad(acc, a.l[i], a2[k - i]);
-        if ((k & 1) == 0) fe_mad(acc, a.l[k / 2], a.l[k / 2]);
-    });
+            for (int i = (k < NL ? 0 : k - NL + 1); 2 * i < k; i++) fe_mad(acc, x[i], a2[k - i]);
+            if ((k & 1) == 0) fe_mad(acc, x[k / 2], x[k / 2]);
+        },
+        [&](uint64_t& accB, uint64_t& accA, uint32_t* mm, auto cnt) { chain_barrier_ops<NL, decltype(cnt)::value>(accB, accA, mm, x); });
 }
 
 // ---- memory / wire formats -----------------------------------------------------------------------
