@@ -324,15 +324,18 @@ BPP_HD void xyzz_madd_lazy(Xyzz<C>& p, const Aff<C>& q, bool neg) {
         p.ZZZ = F::one();
         return;
     }
-    const F U2 = fe_mul(q.x, p.ZZ);                 // < 1.01p
-    const F S2 = fe_mul(q.y, p.ZZZ);                // < 1.01p
-    const F Pp = fe_sub_nr<6>(U2, p.X);             // U2 - X1 + 6p          in (0, 7.1p)
-    const F R = fe_csub_nr<4>(S2, neg, p.Y);        // +-S2 - Y1 + 4p        in (0.9p, 5.1p)
-    const F PP = fe_sqr(Pp);                        // 7.1^2 / 630           < 1.09p
+    // first operands: the one that dies in the product where there is one; the others (the table entry, which the rare
+    // doubling branch reads again, Pp and R) go through the _io forms (field.hpp) and are read back re-defined
+    F qx = q.x, qy = q.y;
+    const F U2 = fe_mul_io(qx, p.ZZ);               // < 1.01p
+    const F S2 = fe_mul_io(qy, p.ZZZ);              // < 1.01p
+    F Pp = fe_sub_nr<6>(U2, p.X);                   // U2 - X1 + 6p          in (0, 7.1p)
+    F R = fe_csub_nr<4>(S2, neg, p.Y);              // +-S2 - Y1 + 4p        in (0.9p, 5.1p)
+    const F PP = fe_sqr_io(Pp);                     // 7.1^2 / 630           < 1.09p
     const F PPP = fe_mul(Pp, PP);                   // < 1.02p
     const F Q = fe_mul(p.X, PP);                    // < 1.02p
     const F u = fe_add_dbl_nr(PPP, Q);              // PPP + 2Q              < 3.1p
-    const F X3 = fe_sub_nr<4>(fe_sqr(R), u);        // R^2 - PPP - 2Q + 4p   in (0.9p, 5.1p)
+    const F X3 = fe_sub_nr<4>(fe_sqr_io(R), u);     // R^2 - PPP - 2Q + 4p   in (0.9p, 5.1p)
     const F T = fe_sub_nr<6>(Q, X3);                // Q - X3 + 6p           in (0.9p, 7.1p)
     const F nY = fe_sub_nr<2>(F::zero(), p.Y);      // 2p - Y1               in [0, 2p]
     const F ZZ3 = fe_mul(p.ZZ, PP);
@@ -343,8 +346,9 @@ BPP_HD void xyzz_madd_lazy(Xyzz<C>& p, const Aff<C>& q, bool neg) {
 #endif
     if (ZZ3.is_zero()) {   // equal x: P + P or P + (-P)   (rare; the reference's case analysis, macros.rs:42-146)
         if (fe_is_zero_mod<5>(R)) {
-            Aff<C> qq = q;
-            if (neg) qq.y = fe_sub_nr<1>(F::zero(), q.y);
+            Aff<C> qq;
+            qq.x = qx;
+            qq.y = neg ? fe_sub_nr<1>(F::zero(), qy) : qy;
             p = xyzz_dbl_aff(qq);
         } else {
             p = xyzz_inf<C>();

@@ -525,18 +525,25 @@ BPP_HD Fe<P> fe_fused_reduce(ColFn&& col, PinFn&& pin) {
 }
 
 // Montgomery product a*b*R^-1 mod p.  For a < alpha p, b < beta p the result is < p (1 + alpha beta / HEADROOM).
+// fe_mul_io: `a` is read AND handed back (same value, re-defined: see chain_barrier_ops) -- for an operand that is
+// needed again afterwards, so that its later readers use the limbs as the multiplication left them and no register
+// copies are made to keep the old ones alive.  fe_mul takes the operand by value-semantics instead: free when `a` dies
+// here (pass the operand that dies first as `a`), NL register moves otherwise.
 template <class P>
-BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+BPP_HD Fe<P> fe_mul_io(Fe<P>& a, const Fe<P>& b) {
     constexpr int NL = P::NL;
-    uint32_t x[NL];   // a's limbs, re-"defined" at every column boundary (chain_barrier_ops): pass the operand that dies first
-#pragma unroll
-    for (int i = 0; i < NL; i++) x[i] = a.l[i];
+    uint32_t* x = a.l;
     return fe_fused_reduce<P, 1>(
         [&](int k, uint64_t& acc) {
 #pragma unroll
             for (int i = (k < NL ? 0 : k - NL + 1); i <= (k < NL ? k : NL - 1); i++) fe_mad(acc, x[i], b.l[k - i]);
         },
         [&](uint64_t& accB, uint64_t& accA, uint32_t* mm, auto cnt) { chain_barrier_ops<NL, decltype(cnt)::value>(accB, accA, mm, x); });
+}
+template <class P>
+BPP_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> x = a;
+    return fe_mul_io(x, b);
 }
 
 // (a*b + c*d) * R^-1 mod p with ONE Montgomery reduction: < p (1 + (alpha beta + gamma delta) / HEADROOM).
@@ -567,14 +574,12 @@ BPP_HD Fe<P> fe_mul_add(const Fe<P>& a, const Fe<P>& b, const Fe<P>& c, const Fe
 // (2 a_j < 2^31: a cross product counts as two plain ones in the column bound, which is what it replaces):
 // 91 v_mad_u64_u32 instead of 169 for the product part.
 template <class P>
-BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+BPP_HD Fe<P> fe_sqr_io(Fe<P>& a) {
     constexpr int NL = P::NL;
-    uint32_t x[NL], a2[NL];
+    uint32_t a2[NL];
+    uint32_t* x = a.l;
 #pragma unroll
-    for (int i = 0; i < NL; i++) {
-        x[i] = a.l[i];
-        a2[i] = a.l[i] << 1;
-    }
+    for (int i = 0; i < NL; i++) a2[i] = a.l[i] << 1;
     return fe_fused_reduce<P, 1>(
         [&](int k, uint64_t& acc) {
             // pairs i < j, i + j = k
@@ -583,6 +588,11 @@ BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
             if ((k & 1) == 0) fe_mad(acc, x[k / 2], x[k / 2]);
         },
         [&](uint64_t& accB, uint64_t& accA, uint32_t* mm, auto cnt) { chain_barrier_ops<NL, decltype(cnt)::value>(accB, accA, mm, x); });
+}
+template <class P>
+BPP_HD Fe<P> fe_sqr(const Fe<P>& a) {
+    Fe<P> x = a;
+    return fe_sqr_io(x);
 }
 
 // ---- memory / wire formats -----------------------------------------------------------------------
