@@ -418,10 +418,14 @@ def main():
             if Bl > Bsz:
                 continue
             wl = bv.workspace_bytes(Bl)
+            bv.set_profiling(True)
             dl = timed(lambda i: bv.run_device(d_pts.data_ptr(), d_sc.data_ptr(), Bl, d_ok.data_ptr(), d_ws.data_ptr(),
                                                max(wl, 1), stream), args.latency_steps, torch, None, dev)
+            lst, _, _ = bv.profile()
+            bv.set_profiling(False)
             assert int(d_ok[:Bl].sum().item()) == 0
-            latency["B=%d" % Bl] = {"ms": dl / args.latency_steps * 1e3, "verifies_per_s": Bl * args.latency_steps / dl}
+            latency["B=%d" % Bl] = {"ms": dl / args.latency_steps * 1e3, "verifies_per_s": Bl * args.latency_steps / dl,
+                                    "stage_ms": {k: round(v, 4) for k, v in lst.items()}}
 
     # ---- the batched prover with every buffer in HBM ---------------------------
     prove = None

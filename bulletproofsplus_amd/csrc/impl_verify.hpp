@@ -42,6 +42,9 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
     // but keep at least four generators per lane so that a block's prologue stays amortised.
     const unsigned b_thr = std::min<unsigned>(cdiv((size_t)32768, count ? count : 1),
                                               std::max<unsigned>(1, s.NF / (FIXED_BLOCK * 4)));
+#ifdef BPP_FORCE_PER   // tuning builds only (A/B of the launch geometry on one box)
+    if (count >= 1024) return std::max(1u, std::min<unsigned>(BPP_FORCE_PER, maxb));
+#endif
     return std::max(1u, std::min(std::max(b_lat, b_thr), maxb));
 }
 
