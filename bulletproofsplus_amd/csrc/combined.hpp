@@ -125,20 +125,20 @@ __global__ void __launch_bounds__(256) k_comb_fixed(VerifyShape s, const uint32_
 }
 
 // out[g][j] = sum over the proofs p of group g (p = g * group + t, t < group, p < count) of in[p][j]
-// (jacobian window sums, VAR_WINDOWS per proof); one lane per (g, j)
+// (jacobian window sums, var_wsums<C>() per proof); one lane per (g, j)
 template <class C>
 __global__ void __launch_bounds__(64) k_comb_window_fold(const uint32_t* __restrict__ in, size_t count, uint32_t group,
                                                          uint32_t* __restrict__ out, size_t n_out) {
     constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const size_t g = i / VAR_WINDOWS;
-    const uint32_t j = (uint32_t)(i % VAR_WINDOWS);
+    const size_t g = i / var_wsums<C>();
+    const uint32_t j = (uint32_t)(i % var_wsums<C>());
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < group; t++) {
         const size_t p = g * group + t;
         if (p >= count) break;
-        acc = jac_add(acc, jac_ldg<C>(in + (p * VAR_WINDOWS + j) * JW));
+        acc = jac_add(acc, jac_ldg<C>(in + (p * var_wsums<C>() + j) * JW));
     }
     jac_stg<C>(out + i * JW, acc);
 }

@@ -417,6 +417,92 @@ BPP_HD bool aff_in_prime_subgroup(const Aff<C>& p) {
     }
 }
 
+// GLV split of a BLS12-381 scalar for the curve's endomorphism: k = k1 + k2 z^2 with k1 = k mod z^2, k2 = k div z^2,
+// both < 2^128 (z^2 has 128 bits, r / z^2 < 2^128), and [z^2] P = -phi(P) = (beta x, -y) on G1.
+// k: 8 words, any value < 2^256 with k / z^2 < 2^128 (every canonical scalar).  The quotient starts from the Barrett
+// estimate floor(floor(k / 2^128) MU / 2^128), MU = floor(2^256 / z^2): at most 2 short (tools/gen_constants.py checks
+// the bound on 200 000 scalars; tests/host/glv_host_test.cpp checks the split against 128-bit integer arithmetic).
+template <class C>
+BPP_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
+    using K = typename C::K;
+    uint32_t q[4];
+    {   // (k[4..8) * MU[0..5)) >> 128: 4 x 5 words, column sums in 64 bits + a carry word
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+        uint32_t prod[9];
+#pragma unroll
+        for (int col = 0; col < 9; col++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int jx = col - i;
+                if (jx < 0 || jx > 4) continue;
+                const uint64_t pr = (uint64_t)k[4 + i] * K::GLV_MU[jx];
+                lo += pr;
+                hi += lo < pr ? 1u : 0u;
+            }
+            prod[col] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = prod[4 + i];
+    }
+    // rem = k - q z^2, low 160 bits (the true remainder is < 3 z^2 < 2^130)
+    uint32_t rem[5];
+    {
+        uint32_t qz[5];
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int col = 0; col < 5; col++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int jx = col - i;
+                if (jx < 0 || jx > 3) continue;
+                const uint64_t pr = (uint64_t)q[i] * K::ZSQW[jx];
+                lo += pr;
+                hi += lo < pr ? 1u : 0u;
+            }
+            qz[col] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const uint64_t d = (uint64_t)k[t] - qz[t] - borrow;
+            rem[t] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+        }
+    }
+    for (int it = 0; it < 3; it++) {   // at most two corrections
+        uint32_t t5[5];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            const uint64_t d = (uint64_t)rem[t] - (t < 4 ? K::ZSQW[t] : 0u) - borrow;
+            t5[t] = (uint32_t)d;
+            borrow = (uint32_t)(d >> 63);
+        }
+        if (!borrow) {   // rem >= z^2
+#pragma unroll
+            for (int t = 0; t < 5; t++) rem[t] = t5[t];
+            uint32_t c = 1;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint64_t x = (uint64_t)q[t] + c;
+                q[t] = (uint32_t)x;
+                c = (uint32_t)(x >> 32);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        k1[t] = rem[t];
+        k2[t] = q[t];
+    }
+}
+
 // Same group element?  (cross-multiplied comparison, no inversion)
 template <class C>
 BPP_HD bool jac_eq(const Jac<C>& p, const Jac<C>& q) {

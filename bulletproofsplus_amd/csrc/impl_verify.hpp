@@ -100,7 +100,7 @@ struct VerifyImpl {
         w.vdig = o;
         o += al(count * s.NV * VAR_DIGIT_STRIDE);                  // 65 digit bytes per proof point
         w.vwsum = o;
-        o += al(count * VAR_WINDOWS * JW * 4);                     // window sums
+        o += al(count * var_wsums<C>() * JW * 4);                     // window sums
         w.vtbl = o;
         o += al(count * s.NV * VAR_MULTIPLES * 2 * N * 4);         // 1P..8P of every proof point, affine
         w.vscr = o;
@@ -181,9 +181,9 @@ struct VerifyImpl {
         w.vscr = o;
         o += al(items * 2 * (VAR_MULTIPLES - 1) * N * 4);
         w.vwsum = o;
-        o += al(count * VAR_WINDOWS * JW * 4);
+        o += al(count * var_wsums<C>() * JW * 4);
         w.vfold = o;
-        o += al((size_t)cdiv(count, COMB_FOLD_GROUP) * VAR_WINDOWS * JW * 4);
+        o += al((size_t)cdiv(count, COMB_FOLD_GROUP) * var_wsums<C>() * JW * 4);
         w.total = o;
         return w;
     }
@@ -363,7 +363,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
     uint8_t* w_vd = ws + L.vdig;
     uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
-    const size_t vlanes = count * VAR_WINDOWS;
+    const size_t vlanes = count * var_wsums<C>();
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
@@ -387,6 +387,13 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
     hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
                        count * folded);
+    if (tree) {   // a small batch waits for latency, not throughput: one block per proof finishes the sum as a tree
+        hipLaunchKernelGGL(k_finalize_tree<C>, dim3((unsigned)count), dim3(64), 0, st, w_fp, folded, w_vp, w_bad, d_ok,
+                           reinterpret_cast<uint32_t*>(d_out_result), count);
+        HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
     hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
                        count * folded2);
     const uint32_t* w_last = w_fp2;
@@ -489,15 +496,15 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
-    const size_t vlanes = count * VAR_WINDOWS;
+    const size_t vlanes = count * var_wsums<C>();
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes);
     uint32_t* cur = w_vw;
     uint32_t* nxt = w_vf;
     for (size_t nrem = count; nrem > 1;) {
         const size_t groups = cdiv(nrem, COMB_FOLD_GROUP);
-        hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * VAR_WINDOWS, 64)), dim3(64), 0, st, cur, nrem,
-                           COMB_FOLD_GROUP, nxt, groups * VAR_WINDOWS);
+        hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * var_wsums<C>(), 64)), dim3(64), 0, st, cur, nrem,
+                           COMB_FOLD_GROUP, nxt, groups * var_wsums<C>());
         std::swap(cur, nxt);
         nrem = groups;
     }

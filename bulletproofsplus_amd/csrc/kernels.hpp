@@ -41,8 +41,25 @@ constexpr unsigned VS_PB = 8;                 // proofs per block of k_vs_expand
 constexpr unsigned VS_BLOCK = VS_PB * 64;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
-constexpr uint32_t VAR_WINDOWS = 65;       // proof-point MSM: 4-bit windows of a 260-bit value
-constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple)
+// Proof-point MSM: signed 4-bit windows.  Plain: 65 windows of a 260-bit value (scalar + bias).  BLS12-381 splits every
+// scalar with the curve's endomorphism first (GLV: k = k1 + k2 z^2, [z^2] P = (beta x, -y); k_var_digits), so a point
+// contributes TWO 128-bit halves and there are 33 windows -- the same number of mixed additions (33 x 2 against 65),
+// but half the ~256 sequential doublings of the Horner stage, which is what a small batch waits for.
+template <class C>
+constexpr bool var_glv() {
+    return C::ID == 0;
+}
+template <class C>
+constexpr uint32_t var_windows() {
+    return var_glv<C>() ? 33u : 65u;
+}
+// window sums k_var_windows writes per proof: [half][window] (one lane each, so that a lone proof does not wait for
+// 2 x NV sequential additions); the Horner stage adds the two halves of a window as it reads them
+template <class C>
+constexpr uint32_t var_wsums() {
+    return var_windows<C>() * (var_glv<C>() ? 2u : 1u);
+}
+constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple): 65, or 2 x 33
 constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P .. 8P
 // minimum waves per SIMD the register allocator must leave room for (512 VGPRs / waves)
 #ifndef BPP_FIXED_WAVES
@@ -699,19 +716,30 @@ __global__ void __launch_bounds__(64, 1) k_tbl_fill(VerifyShape s, uint32_t* __r
 // Alone on the chip this is 128 waves of pure latency, so it does not get a launch of its own: the first
 // `horner_blocks` blocks of k_fixed_msm's grid run it, beside the blocks that do the fixed-generator sums
 // (one lane per proof; for small batches one wave per proof: var_horner_wave).
+// window sum j of proof b: S_j = (half 0) [+ (half 1)]
+template <class C>
+__device__ __forceinline__ Jac<C> var_wsum_ld(const uint32_t* __restrict__ wsum, size_t b, uint32_t j) {
+    constexpr int JW = jac_words<C>();
+    constexpr uint32_t NW = var_windows<C>();
+    const uint32_t* W = wsum + b * var_wsums<C>() * JW;
+    Jac<C> sj = jac_ldg<C>(W + (size_t)j * JW);
+    if constexpr (var_glv<C>()) sj = jac_add(sj, jac_ldg<C>(W + (size_t)(NW + j) * JW));
+    return sj;
+}
+
 template <class C>
 __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b) {
     constexpr int JW = jac_words<C>();
-    const uint32_t* W = wsum + b * VAR_WINDOWS * JW;
-    Jac<C> acc = jac_ldg<C>(W + (size_t)(VAR_WINDOWS - 1) * JW);
-    for (int j = (int)VAR_WINDOWS - 2; j >= 0; j--) {
+    constexpr uint32_t NW = var_windows<C>();
+    Jac<C> acc = var_wsum_ld<C>(wsum, b, NW - 1);
+    for (int j = (int)NW - 2; j >= 0; j--) {
         if (!acc.is_inf()) {
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
         }
-        acc = jac_add(acc, jac_ldg<C>(W + (size_t)j * JW));
+        acc = jac_add(acc, var_wsum_ld<C>(wsum, b, (uint32_t)j));
     }
     jac_stg<C>(out + b * JW, acc);
 }
@@ -723,13 +751,13 @@ __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsu
 template <class C>
 __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
                                                 uint32_t* lds_wave) {
-    static_assert(VAR_WINDOWS == 65, "64 lanes + the carry window");
+    constexpr uint32_t NW = var_windows<C>(), L = NW - 1;   // L lanes + the carry window
+    static_assert(L == 64 || L == 32, "a power of two of lanes within one wave");
     constexpr int JW = jac_words<C>();
     const uint32_t j = threadIdx.x & 63u;
-    const uint32_t* W = wsum + b * VAR_WINDOWS * JW;
-    Jac<C> acc = jac_ldg<C>(W + (size_t)j * JW);
-    if (j == 63) {   // the 65th window joins the 64th slot: S_63 + 16 * S_64
-        Jac<C> t = jac_ldg<C>(W + (size_t)64 * JW);
+    Jac<C> acc = j < L ? var_wsum_ld<C>(wsum, b, j) : jac_inf<C>();
+    if (j == L - 1) {   // the last window joins the slot before it: S_{L-1} + 16 * S_L
+        Jac<C> t = var_wsum_ld<C>(wsum, b, L);
         if (!t.is_inf()) {
             t = jac_dbl(t);
             t = jac_dbl(t);
@@ -740,11 +768,11 @@ __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsu
     }
     // the exchange stays inside the wave: LDS serves a wave's accesses in order, so a wavefront-scope fence (for the
     // compiler) is all the synchronisation it needs -- no block barrier, and an idle second wave can simply leave
-    for (uint32_t stride = 1; stride < 64; stride <<= 1) {
+    for (uint32_t stride = 1; stride < L; stride <<= 1) {
         jac_store(acc, lds_wave + (size_t)j * JW);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if ((j & (2 * stride - 1)) == 0) {
+        if ((j & (2 * stride - 1)) == 0 && j + stride < L) {
             Jac<C> hi = jac_load<C>(lds_wave + (size_t)(j + stride) * JW);
             if (!hi.is_inf())
                 for (uint32_t t = 0; t < 4 * stride; t++) hi = jac_dbl(hi);
@@ -1046,25 +1074,51 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
     if (item >= items) return;
     const size_t b = item / s.NV;
     const uint32_t v = (uint32_t)(item % s.NV);
-    uint32_t w[9];
-    ld_words<8>(scalars + (flat ? item : b * s.N + var_term_index(s, v)) * 8, w);
-    w[8] = 0;
-    uint32_t carry = 0;
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const uint32_t kw = t < 8 ? 0x88888888u : 0x8u;
-        uint64_t x = (uint64_t)w[t] + kw + carry;
-        w[t] = (uint32_t)x;
-        carry = (uint32_t)(x >> 32);
-    }
-    // digit j = nibble j minus 8, stored biased (nibble itself): 0..15, 8 means digit 0
+    uint32_t k[8];
+    ld_words<8>(scalars + (flat ? item : b * s.N + var_term_index(s, v)) * 8, k);
     uint32_t out[VAR_DIGIT_STRIDE / 4];
 #pragma unroll
     for (int t = 0; t < (int)(VAR_DIGIT_STRIDE / 4); t++) out[t] = 0;
+    // digit j of a value = nibble j of (value + 0x88..8) minus 8, stored biased (the nibble itself): 0..15, 8 means 0
+    if constexpr (var_glv<C>()) {
+        uint32_t rem[4], q[4];
+        glv_split<C>(k, rem, q);   // k = rem + q z^2, both < 2^128 (ec.hpp)
+        // 33 biased nibbles of each half: k1 at byte 0.., k2 at byte 33..
 #pragma unroll
-    for (int j = 0; j < (int)VAR_WINDOWS; j++) {
-        const uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
-        out[j >> 2] |= nib << ((j & 3) * 8);
+        for (int h = 0; h < 2; h++) {
+            uint32_t w[5];
+            uint32_t carry = 0;
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+                const uint64_t x = (uint64_t)(t < 4 ? (h ? q[t] : rem[t]) : 0u) + (t < 4 ? 0x88888888u : 0x8u) + carry;
+                w[t] = (uint32_t)x;
+                carry = (uint32_t)(x >> 32);
+            }
+#pragma unroll
+            for (int j = 0; j < 33; j++) {
+                const uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
+                const int byte = h * 33 + j;
+                out[byte >> 2] |= nib << ((byte & 3) * 8);
+            }
+        }
+    } else {
+        uint32_t w[9];
+#pragma unroll
+        for (int t = 0; t < 8; t++) w[t] = k[t];
+        w[8] = 0;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const uint32_t kw = t < 8 ? 0x88888888u : 0x8u;
+            uint64_t x = (uint64_t)w[t] + kw + carry;
+            w[t] = (uint32_t)x;
+            carry = (uint32_t)(x >> 32);
+        }
+#pragma unroll
+        for (int j = 0; j < (int)var_windows<C>(); j++) {
+            const uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
+            out[j >> 2] |= nib << ((j & 3) * 8);
+        }
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(digits + item * VAR_DIGIT_STRIDE);
     st_words<VAR_DIGIT_STRIDE / 4>(dst, out);
@@ -1093,7 +1147,7 @@ __global__ void __launch_bounds__(VAR_BLOCK, 1) k_var_tables(const uint32_t* __r
     affine_chain<C>(aff_dbl(p), p, M - 1, T + 2 * N, S);   // 2P .. 8P
 }
 
-// lane = (proof b, window j): wsum[lane] = sum_v sign * T[b][v][|digit| - 1]
+// lane = (proof b, half h, window j): wsum[lane] = sum_v sign * T[b][v][|digit| - 1]   (half 1: of (beta x, -y))
 template <class C>
 __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(VerifyShape s, const uint8_t* __restrict__ digits,
                                                                          const uint32_t* __restrict__ tables,
@@ -1102,11 +1156,19 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
     constexpr int JW = jac_words<C>();
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
-    const size_t b = lane / VAR_WINDOWS;
-    const uint32_t j = (uint32_t)(lane % VAR_WINDOWS);
-    const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + j;
+    constexpr uint32_t NW = var_windows<C>();
+    constexpr uint32_t H = var_glv<C>() ? 2u : 1u;   // scalar halves per point (GLV: k1 on P, k2 on (beta x, -y))
+    const size_t b = lane / (NW * H);
+    const uint32_t h = (uint32_t)(lane / NW) % H;
+    const uint32_t j = (uint32_t)(lane % NW);
+    const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + h * NW + j;   // half h's digits sit NW bytes after half 0's
     const uint32_t* T = tables + b * s.NV * VAR_MULTIPLES * 2 * N;
     Xyzz<C> acc = xyzz_inf<C>();
+    Fe<typename C::Fp> beta;
+    if constexpr (var_glv<C>()) {
+#pragma unroll
+        for (int i = 0; i < C::Fp::NL; i++) beta.l[i] = C::K::BETA[i];
+    }
     // one entry in flight: the gather of point v + 1 is issued before the addition of point v
     uint32_t raw[2 * N];
     int32_t d_next = (int32_t)dg[0] - 8;
@@ -1120,7 +1182,15 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
             if (d_next)
                 ld_words<2 * N>(T + ((size_t)(v + 1) * VAR_MULTIPLES + (d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
         }
-        if (d) xyzz_madd_lazy(acc, cur, d < 0);
+        bool neg = d < 0;
+        if constexpr (var_glv<C>()) {
+            if (d && h) {   // [z^2] T = (beta x, -y); infinity (x = y = 0) stays infinity
+                cur.x = fe_mul(cur.x, beta);
+                fe_cond_sub_p(cur.x);
+                neg = !neg;
+            }
+        }
+        if (d) xyzz_madd_lazy(acc, cur, neg);
     }
     jac_stg<C>(wsum + lane * JW, xyzz_to_jac(acc));
 }
@@ -1141,6 +1211,33 @@ __global__ void __launch_bounds__(64) k_finalize(const uint32_t* __restrict__ fi
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < per; t++) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * JW));
     for (uint32_t t = 0; t < nv; t++) acc = jac_add(acc, jac_ldg<C>(var_partials + (b * nv + t) * JW));
+    ok[b] = (jac_is_identity_class(acc) && !bad[b]) ? 0u : 1u;
+    if (wire_result) {
+        uint32_t w[2 * N + 2];
+        aff_to_wire(jac_to_aff(acc), w);
+#pragma unroll
+        for (int t = 0; t < 2 * N + 2; t++) wire_result[b * (2 * N + 2) + t] = w[t];
+    }
+}
+
+// The same for a batch too small to fill the chip (count <= HORNER_TREE_MAX): one 64-lane block per proof over the
+// proof's `per` partials (the first fold pass's output) -- strided serial sums, then an LDS tree: ceil(per / 64) + 6
+// additions deep instead of the ~25 of the remaining fold passes + k_finalize, which a lone proof would wait for.
+template <class C>
+__global__ void __launch_bounds__(64) k_finalize_tree(const uint32_t* __restrict__ fixed_partials, uint32_t per,
+                                                      const uint32_t* __restrict__ var_partials,
+                                                      const uint32_t* __restrict__ bad, uint32_t* __restrict__ ok,
+                                                      uint32_t* __restrict__ wire_result, size_t count) {
+    constexpr int N = C::Fp::N;
+    constexpr int JW = jac_words<C>();
+    __shared__ __align__(16) uint32_t lds[64 * JW];
+    const size_t b = blockIdx.x;
+    if (b >= count) return;
+    Jac<C> acc = jac_inf<C>();
+    for (uint32_t t = threadIdx.x; t < per; t += 64) acc = jac_add(acc, jac_ldg<C>(fixed_partials + (b * per + t) * JW));
+    acc = block_reduce_jac<C>(acc, lds);
+    if (threadIdx.x != 0) return;
+    acc = jac_add(acc, jac_ldg<C>(var_partials + b * JW));
     ok[b] = (jac_is_identity_class(acc) && !bad[b]) ? 0u : 1u;
     if (wire_result) {
         uint32_t w[2 * N + 2];

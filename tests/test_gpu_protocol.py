@@ -123,9 +123,14 @@ def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
     p2 = pts.copy(); p2[3] = pts[4] if pts.shape[0] > 4 else opk.gh[1]; add(p2, sc, V)  # L_0 replaced
     V2 = V.copy(); V2[-1] = O.point_neg(cid, V[-1]); add(pts, sc, V2)                  # commitment negated
     p2 = pts.copy(); p2[1] = O.point_to_wire(cid, None); add(p2, sc, V)                # wip.A = infinity
+    outside_g1 = []
     if cname == "bls12_381":
         # (0, 2) lies on y^2 = x^3 + 4 but has order 3 (outside G1): its multiples reach infinity inside the
-        # proof-point tables (k_var_tables); the group law must still agree with the oracle's
+        # proof-point tables (k_var_tables) and must be handled.  Such a point is not an element of the protocol's group:
+        # the engine evaluates the proof-point MulVec with G1's endomorphism (GLV, kernels.hpp k_var_digits), which
+        # equals sum s_i P_i exactly on G1 and is merely deterministic outside it -- so for these two records the verdict
+        # (reject) is compared, not the full-curve sum the oracle computes.  The serialized path rejects them at decode.
+        outside_g1 = [len(recs), len(recs) + 1]
         p2 = pts.copy(); p2[2] = O.point_to_wire(cid, (0, 2)); add(p2, sc, V)
         bls_p = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
         p2 = pts.copy(); p2[0] = O.point_to_wire(cid, (0, bls_p - 2)); add(p2, sc, V)      # its negative, as A
@@ -139,7 +144,8 @@ def test_batch_verifier_small_bit_exact(cname, n, vals, gams, c):
     assert ok.tolist() == exp_rc
     for i in range(len(recs)):
         assert np.array_equal(got_sc[i], exp_sc[i]), i
-        assert np.array_equal(got_res[i], exp_res[i]), i
+        if i not in outside_g1:
+            assert np.array_equal(got_res[i], exp_res[i]), i
     # host-pointer entry point gives the same verdicts
     assert bv.verify_wire(np.stack(recs), np.stack(scs)).tolist() == exp_rc
     # an off-curve point makes that proof (only) fail
