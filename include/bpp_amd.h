@@ -152,7 +152,11 @@ size_t bpp_verifier_table_bytes(const bpp_verifier *v);
  * Optional debug / parity outputs (NULL to skip):
  *   d_out_scalars: count x N scalars -- the MulVec scalars in the reference's MulVec order
  *                  (range/mod.rs:481-490 for m > 1, wip.rs:298-307 for m == 1)
- *   d_out_result : count x wire point -- the MulVec result ("expected", range/mod.rs:503) */
+ *   d_out_result : count x wire point -- the MulVec result ("expected", range/mod.rs:503)
+ * Points are elements of the prime-order group (what the prover, mcl, or the decoder with its subgroup check produce).
+ * On BLS12-381 the proof-carried points are multiplied through G1's endomorphism (GLV, as mcl itself does): for points
+ * of G1 the result is sum s_i P_i bit for bit; a curve point OUTSIDE G1 is still processed deterministically and its
+ * proof judged by the same equation, but the result point is then not the full-curve sum. */
 int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
                      const uint64_t *d_challenges, uint32_t *d_ok, void *d_workspace,
                      size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
