@@ -32,16 +32,29 @@ constexpr int compressed_bytes() {
     return C::ID == 0 ? 48 : (C::ID == 1 ? 33 : 32);
 }
 
-// a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4 (MSB-first square-and-multiply over the
-// public constant P::SQRTW); the caller checks the result by squaring
+// a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4; the caller checks the result by squaring.
+// Fixed 4-bit windows over the public constant P::SQRTW, most significant first: 14 products for the table a^2..a^15
+// (a local array the window digit indexes: it lives in private memory, not in registers), then four squarings and at
+// most one product per window -- 378 S + 95 + 14 M for BLS12-381 against 378 S + 228 M bit by bit ((p+1)/4 has 229 one
+// bits), 253 S + 78 M against 253 S + 246 M for secp256k1.
 template <class P>
 BPP_HD Fe<P> fe_sqrt_3mod4(const Fe<P>& a) {
+    Fe<P> tbl[16];
+    tbl[0] = Fe<P>::one();
+    tbl[1] = a;
+    for (int i = 2; i < 16; i++) tbl[i] = fe_mul(tbl[i - 1], a);
     Fe<P> acc = Fe<P>::one();
     bool started = false;
-    for (int i = P::N * 32 - 1; i >= 0; i--) {
-        if (started) acc = fe_sqr(acc);
-        if ((P::SQRTW[i >> 5] >> (i & 31)) & 1u) {
-            acc = started ? fe_mul(acc, a) : a;
+    for (int w = P::N * 8 - 1; w >= 0; w--) {
+        const uint32_t d = (P::SQRTW[w >> 3] >> ((w & 7) * 4)) & 15u;
+        if (started) {
+            acc = fe_sqr(acc);
+            acc = fe_sqr(acc);
+            acc = fe_sqr(acc);
+            acc = fe_sqr(acc);
+        }
+        if (d) {
+            acc = started ? fe_mul(acc, tbl[d]) : tbl[d];
             started = true;
         }
     }
@@ -192,7 +205,7 @@ __device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __rest
 
 // one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (see point_decompress)
 template <class C>
-__global__ void __launch_bounds__(64) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
+__global__ void __launch_bounds__(64, 2) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
                                                           uint32_t* __restrict__ ok, size_t n, uint32_t check_subgroup) {
     constexpr int N = C::Fp::N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -212,7 +225,7 @@ __host__ __device__ constexpr size_t container_bytes(uint32_t k) {
 // bpp_verifier_run reads.  The lane of a proof's first point also checks the header and the canonicity of r', s',
 // delta' and copies them out.  status[p] (zeroed by the caller) becomes non-zero when anything of proof p is rejected.
 template <class C>
-__global__ void __launch_bounds__(64) k_container_decode(VerifyShape s, const uint8_t* __restrict__ proofs,
+__global__ void __launch_bounds__(64, 2) k_container_decode(VerifyShape s, const uint8_t* __restrict__ proofs,
                                                          const uint8_t* __restrict__ commitments,
                                                          uint32_t* __restrict__ records, uint32_t* __restrict__ scalars,
                                                          uint32_t* __restrict__ status, size_t count) {

@@ -393,8 +393,12 @@ BPP_HD bool aff_in_prime_subgroup(const Aff<C>& p) {
     if constexpr (C::ID == 0) {
         using F = Fe<typename C::Fp>;
         if (p.is_inf()) return true;
-        Jac<C> t = jac_from_aff(p);
-        for (int pass = 0; pass < 2; pass++) {   // t <- [|z|] t, twice
+        Jac<C> t = jac_inf<C>();
+        for (int i = 63; i >= 0; i--) {   // t <- [|z|] P: the base is affine, every addition a mixed one
+            t = jac_dbl(t);
+            if ((C::K::ZABS >> i) & 1ull) t = jac_madd(t, p);
+        }
+        {   // t <- [|z|] t
             const Jac<C> base = t;
             Jac<C> acc = jac_inf<C>();
             for (int i = 63; i >= 0; i--) {
