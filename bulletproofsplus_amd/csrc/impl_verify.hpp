@@ -3,6 +3,7 @@
 #pragma once
 #include "codec.hpp"
 #include "combined.hpp"
+#include "fixed_launch.hpp"
 #include "host_util.hpp"
 #include "pippenger.hpp"
 #include "prover_batch.hpp"
@@ -46,12 +47,6 @@ inline unsigned blocks_per_proof(const VerifyShape& s, size_t count) {
     if (count >= 1024) return std::max(1u, std::min<unsigned>(BPP_FORCE_PER, maxb));
 #endif
     return std::max(1u, std::min(std::max(b_lat, b_thr), maxb));
-}
-
-// dynamic LDS of a k_fixed_msm launch: the gather ring, reused by the block reduction of ROLE 1
-template <class C>
-constexpr unsigned fixed_lds() {
-    return std::max<unsigned>(fixed_lds_bytes<C>(), FIXED_BLOCK * jac_words<C>() * 4);
 }
 
 // The wave-per-proof (tree) Horner serves the batches too small to fill the chip: one block per proof, so that the
@@ -376,8 +371,8 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
     const unsigned hb = tree ? (unsigned)count : cdiv(count, FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
-    hipLaunchKernelGGL(k_fixed_msm<C>, dim3((unsigned)(hb + count * bpp_)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                       w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree, VpSel{1u, 0u, 1u, 0u});
+    launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree,
+                           VpSel{1u, 0u, 1u, 0u});
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
     // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
@@ -510,9 +505,8 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     }
     // the collapsed fixed-generator MulVec (one "virtual proof") with the Horner lane over the 65 sums in its
     // leading block; the Horner result lands behind the block sums
-    hipLaunchKernelGGL((k_fixed_msm<C, 1>), dim3(1 + L.fixed_blocks), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s, w_cs,
-                       v->table.u32(), w_fp, L.fixed_blocks, 1u, cur, w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u,
-                       VpSel{1u, 0u, 1u, 0u});
+    launch_fixed_msm<C, 1>(1 + L.fixed_blocks, st, s, w_cs, v->table.u32(), w_fp, L.fixed_blocks, 1u, cur,
+                           w_fp + (size_t)L.fixed_blocks * JW, (size_t)1, 1u, VpSel{1u, 0u, 1u, 0u});
     hipLaunchKernelGGL(k_comb_sum_partials<C>, dim3(1), dim3(64), 0, st, w_fp, L.fixed_blocks + 1, (uint32_t)JW, 0u, d_ok,
                        d_out_partial);
     hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
@@ -551,9 +545,8 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
             const size_t nv = cnt * sel.cnt;
             // never more blocks per virtual proof than the workspace was sized for
             const unsigned per = std::min(L.per, blocks_per_proof(s, nv));
-            hipLaunchKernelGGL((k_fixed_msm<C, 2>), dim3((unsigned)(nv * per)), dim3(FIXED_BLOCK), fixed_lds<C>(), st, s,
-                               W(L.vps), v->table.u32(), W(L.part), per, 0u, (const uint32_t*)nullptr,
-                               (uint32_t*)nullptr, (size_t)0, 0u, sel);
+            launch_fixed_msm<C, 2>((unsigned)(nv * per), st, s, W(L.vps), v->table.u32(), W(L.part), per, 0u,
+                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)0, 0u, sel);
             // per-thread partials -> 16 -> 4 per block with every lane busy (as the verifier does); k_pb_collect adds
             // the 4 * per that are left of each MulVec
             const size_t f1 = nv * per * (FIXED_BLOCK / FOLD_GROUP), f2 = f1 / FOLD_GROUP2;
