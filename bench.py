@@ -655,7 +655,10 @@ def main():
         ostep(0)
         torch.cuda.synchronize()
         assert int(d_ok_o.sum().item()) == 0, "%s (%d,%d): a valid proof failed to verify" % (curve, n_, m_)
+        bv_o.set_profiling(True)
         odt = timed(ostep, steps, torch, dist, coll_dev)
+        ost, _, obpp = bv_o.profile()
+        bv_o.set_profiling(False)
         # and one tampered proof in the middle of the batch must be the only one rejected
         sc_bad = scs_o.copy()
         sc_bad[batch // 2, 1, 0] ^= np.uint64(4)
@@ -665,7 +668,8 @@ def main():
         got = d_ok_o.cpu().numpy()
         assert got[batch // 2] == 1 and int(got.sum()) == 1, "%s (%d,%d): tampered proof not singled out" % (curve, n_, m_)
         res = {"value": world * batch * steps / odt, "unit": "verifies/s", "steps": steps, "ms_per_step": odt / steps * 1e3,
-               "batch": batch, "window_bits": window_bits, "table_bytes": bv_o.table_bytes, "msm_terms_per_verify": bv_o.msm_len}
+               "batch": batch, "window_bits": window_bits, "table_bytes": bv_o.table_bytes, "msm_terms_per_verify": bv_o.msm_len,
+               "stage_ms": {k: round(v, 4) for k, v in ost.items()}, "blocks_per_proof": obpp}
         bv_o.close()
         del d_ws_o, d_pts_o, d_sc_o, d_sc_b
         torch.cuda.empty_cache()

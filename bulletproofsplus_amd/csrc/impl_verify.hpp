@@ -358,17 +358,18 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     // sequence); its latency-bound Horner stage rides in the first blocks of the fixed-generator launch
     uint8_t* w_vd = ws + L.vdig;
     uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
-    const size_t vlanes = count * var_wsums<C>();
+    // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree); the tree
+    // reads the window sums split by scalar half (k_var_windows)
+    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
+    const size_t vlanes = count * (tree ? var_wsums<C>() : var_windows<C>());
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                        reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                       vlanes);
+                       vlanes, tree);
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-    // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree)
-    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
     const unsigned hb = tree ? (unsigned)count : cdiv(count, FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
     launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree,
@@ -493,7 +494,7 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
     const size_t vlanes = count * var_wsums<C>();
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                       vlanes);
+                       vlanes, 1u);
     uint32_t* cur = w_vw;
     uint32_t* nxt = w_vf;
     for (size_t nrem = count; nrem > 1;) {

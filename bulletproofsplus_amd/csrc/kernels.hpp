@@ -716,14 +716,14 @@ __global__ void __launch_bounds__(64, 1) k_tbl_fill(VerifyShape s, uint32_t* __r
 // Alone on the chip this is 128 waves of pure latency, so it does not get a launch of its own: the first
 // `horner_blocks` blocks of k_fixed_msm's grid run it, beside the blocks that do the fixed-generator sums
 // (one lane per proof; for small batches one wave per proof: var_horner_wave).
-// window sum j of proof b: S_j = (half 0) [+ (half 1)]
-template <class C>
+// window sum j of proof b.  SPLIT (the layout k_var_windows writes for the tree Horner): S_j = (half 0) + (half 1)
+template <class C, bool SPLIT>
 __device__ __forceinline__ Jac<C> var_wsum_ld(const uint32_t* __restrict__ wsum, size_t b, uint32_t j) {
     constexpr int JW = jac_words<C>();
     constexpr uint32_t NW = var_windows<C>();
-    const uint32_t* W = wsum + b * var_wsums<C>() * JW;
+    const uint32_t* W = wsum + b * (SPLIT ? var_wsums<C>() : NW) * JW;
     Jac<C> sj = jac_ldg<C>(W + (size_t)j * JW);
-    if constexpr (var_glv<C>()) sj = jac_add(sj, jac_ldg<C>(W + (size_t)(NW + j) * JW));
+    if constexpr (SPLIT && var_glv<C>()) sj = jac_add(sj, jac_ldg<C>(W + (size_t)(NW + j) * JW));
     return sj;
 }
 
@@ -731,7 +731,7 @@ template <class C>
 __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b) {
     constexpr int JW = jac_words<C>();
     constexpr uint32_t NW = var_windows<C>();
-    Jac<C> acc = var_wsum_ld<C>(wsum, b, NW - 1);
+    Jac<C> acc = var_wsum_ld<C, false>(wsum, b, NW - 1);
     for (int j = (int)NW - 2; j >= 0; j--) {
         if (!acc.is_inf()) {
             acc = jac_dbl(acc);
@@ -739,7 +739,7 @@ __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsu
             acc = jac_dbl(acc);
             acc = jac_dbl(acc);
         }
-        acc = jac_add(acc, var_wsum_ld<C>(wsum, b, (uint32_t)j));
+        acc = jac_add(acc, var_wsum_ld<C, false>(wsum, b, (uint32_t)j));
     }
     jac_stg<C>(out + b * JW, acc);
 }
@@ -755,9 +755,9 @@ __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsu
     static_assert(L == 64 || L == 32, "a power of two of lanes within one wave");
     constexpr int JW = jac_words<C>();
     const uint32_t j = threadIdx.x & 63u;
-    Jac<C> acc = j < L ? var_wsum_ld<C>(wsum, b, j) : jac_inf<C>();
+    Jac<C> acc = j < L ? var_wsum_ld<C, true>(wsum, b, j) : jac_inf<C>();
     if (j == L - 1) {   // the last window joins the slot before it: S_{L-1} + 16 * S_L
-        Jac<C> t = var_wsum_ld<C>(wsum, b, L);
+        Jac<C> t = var_wsum_ld<C, true>(wsum, b, L);
         if (!t.is_inf()) {
             t = jac_dbl(t);
             t = jac_dbl(t);
@@ -1147,21 +1147,27 @@ __global__ void __launch_bounds__(VAR_BLOCK, 1) k_var_tables(const uint32_t* __r
     affine_chain<C>(aff_dbl(p), p, M - 1, T + 2 * N, S);   // 2P .. 8P
 }
 
-// lane = (proof b, half h, window j): wsum[lane] = sum_v sign * T[b][v][|digit| - 1]   (half 1: of (beta x, -y))
+// split = 1: lane = (proof b, half h, window j), wsum[lane] = sum_v sign * T[b][v][|digit| - 1]   (half 1: of (beta x, -y))
+//            -- the layout of the wave-tree Horner (small batches, the combined check), where nobody should wait for
+//            2 NV additions in a row;
+// split = 0: lane = (proof b, window j) adds both halves of every point itself, wsum holds var_windows sums per proof --
+//            the layout of the one-lane-per-proof Horner, which then has one addition per window on its chain, not two.
 template <class C>
 __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(VerifyShape s, const uint8_t* __restrict__ digits,
                                                                          const uint32_t* __restrict__ tables,
-                                                                         uint32_t* __restrict__ wsum, size_t lanes) {
+                                                                         uint32_t* __restrict__ wsum, size_t lanes,
+                                                                         uint32_t split) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= lanes) return;
     constexpr uint32_t NW = var_windows<C>();
     constexpr uint32_t H = var_glv<C>() ? 2u : 1u;   // scalar halves per point (GLV: k1 on P, k2 on (beta x, -y))
-    const size_t b = lane / (NW * H);
-    const uint32_t h = (uint32_t)(lane / NW) % H;
+    const uint32_t HL = split ? 1u : H;              // halves this lane adds
+    const size_t b = lane / (NW * (H / HL));
+    const uint32_t h0 = split ? (uint32_t)(lane / NW) % H : 0u;
     const uint32_t j = (uint32_t)(lane % NW);
-    const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + h * NW + j;   // half h's digits sit NW bytes after half 0's
+    const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + j;   // half h's digits sit h * NW bytes further
     const uint32_t* T = tables + b * s.NV * VAR_MULTIPLES * 2 * N;
     Xyzz<C> acc = xyzz_inf<C>();
     Fe<typename C::Fp> beta;
@@ -1169,22 +1175,29 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
 #pragma unroll
         for (int i = 0; i < C::Fp::NL; i++) beta.l[i] = C::K::BETA[i];
     }
-    // one entry in flight: the gather of point v + 1 is issued before the addition of point v
+    // item u = (point u / HL, half h0 + u % HL); one entry in flight: the gather of item u + 1 is issued before the
+    // addition of item u
+    const uint32_t items = s.NV * HL;
+    auto digit_of = [&](uint32_t u) -> int32_t {
+        return (int32_t)dg[(size_t)(u / HL) * VAR_DIGIT_STRIDE + (h0 + u % HL) * NW] - 8;
+    };
+    auto entry_of = [&](uint32_t u, int32_t d) -> const uint32_t* {
+        return T + ((size_t)(u / HL) * VAR_MULTIPLES + (d < 0 ? -d : d) - 1) * 2 * N;
+    };
     uint32_t raw[2 * N];
-    int32_t d_next = (int32_t)dg[0] - 8;
-    if (d_next) ld_words<2 * N>(T + (size_t)((d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
-    for (uint32_t v = 0; v < s.NV; v++) {
+    int32_t d_next = digit_of(0);
+    if (d_next) ld_words<2 * N>(entry_of(0, d_next), raw);
+    for (uint32_t u = 0; u < items; u++) {
         const int32_t d = d_next;
         Aff<C> cur;
         if (d) cur = aff_load<C>(raw);
-        if (v + 1 < s.NV) {
-            d_next = (int32_t)dg[(size_t)(v + 1) * VAR_DIGIT_STRIDE] - 8;
-            if (d_next)
-                ld_words<2 * N>(T + ((size_t)(v + 1) * VAR_MULTIPLES + (d_next < 0 ? -d_next : d_next) - 1) * 2 * N, raw);
+        if (u + 1 < items) {
+            d_next = digit_of(u + 1);
+            if (d_next) ld_words<2 * N>(entry_of(u + 1, d_next), raw);
         }
         bool neg = d < 0;
         if constexpr (var_glv<C>()) {
-            if (d && h) {   // [z^2] T = (beta x, -y); infinity (x = y = 0) stays infinity
+            if (d && ((h0 + u % HL) & 1u)) {   // [z^2] T = (beta x, -y); infinity (x = y = 0) stays infinity
                 cur.x = fe_mul(cur.x, beta);
                 fe_cond_sub_p(cur.x);
                 neg = !neg;
