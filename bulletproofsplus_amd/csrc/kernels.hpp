@@ -68,6 +68,9 @@ constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P 
 #ifndef BPP_VAR_WAVES
 #define BPP_VAR_WAVES 2
 #endif
+#ifndef BPP_VAR_TABLES_WAVES
+#define BPP_VAR_TABLES_WAVES 1
+#endif
 
 // ---- small helpers -----------------------------------------------------------------------------------
 
@@ -1127,7 +1130,7 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
 // lane = (proof, point).  tables: [lane][8] affm.  scratch: [lane][14] field elements (Z_k and their prefix
 // products, k = 2..8).
 template <class C>
-__global__ void __launch_bounds__(VAR_BLOCK, 1) k_var_tables(const uint32_t* __restrict__ proof_pts,
+__global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_TABLES_WAVES) k_var_tables(const uint32_t* __restrict__ proof_pts,
                                                                         uint32_t* __restrict__ tables,
                                                                         uint32_t* __restrict__ scratch, size_t lanes) {
     using P = typename C::Fp;
