@@ -53,6 +53,12 @@ BPP_HD F konst(const uint32_t* c) {
     for (int i = 0; i < EdFp::NL; i++) r.l[i] = c[i];
     return r;
 }
+BPP_HD F select(bool c, const F& a, const F& b) {
+    F r;
+#pragma unroll
+    for (int i = 0; i < EdFp::NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
 }  // namespace ed
 
 template <>
@@ -181,10 +187,32 @@ BPP_HD Xyzz<Ed25519> xyzz_madd(const Xyzz<Ed25519>& p, const Aff<Ed25519>& q) {
     r.e = jac_madd(p.e, q);
     return r;
 }
-// acc += (neg ? -q : q): the Edwards addition is complete and has no exceptional cases to defer, so the
-// "lazy" entry point of the MSM loops is the plain unified addition here
+// acc += (neg ? -q : q): the unified addition above (complete: no exceptional cases to defer) with its eight sums and
+// differences left UNREDUCED -- R / p = 2^15 for this field, so nothing below comes near the bound of a Montgomery
+// product -- and the sign of q folded in without a negation: -q = (-x, y) makes y - x and y + x change places and flips
+// the sign of x y, i.e. F = D - C and G = D + C change places.  Inputs: coordinates of p below 1.01 p (products),
+// q canonical.  Multiples of p each value stays below are in the comments; every product has alpha * beta <= 14.
 BPP_HD void xyzz_madd_lazy(Xyzz<Ed25519>& p, const Aff<Ed25519>& q, bool neg) {
-    p.e = jac_madd(p.e, neg ? aff_neg(q) : q);
+    using F = ed::F;
+    Jac<Ed25519>& e = p.e;
+    const F qm = fe_sub_nr<1>(q.y, q.x);       // y2 - x2 + p            (0, 2p)
+    const F qp = fe_add_nr(q.y, q.x);          //                        < 2p
+    const F a1 = fe_sub_nr<2>(e.Y, e.X);       // Y1 - X1 + 2p           (0.9p, 3.1p)
+    const F b1 = fe_add_nr(e.Y, e.X);          //                        < 2.1p
+    const F A = fe_mul(a1, ed::select(neg, qp, qm));
+    const F B = fe_mul(b1, ed::select(neg, qm, qp));
+    const F C = fe_mul(fe_mul(e.T, ed::konst(Ed25519Consts::D2)), fe_mul(q.x, q.y));   // +- C: the sign is in F / G below
+    const F D = fe_add_nr(e.Z, e.Z);           // 2 Z1                   < 2.1p
+    F E = fe_sub_nr<2>(B, A);                  // B - A + 2p             < 3.1p
+    const F H = fe_add_nr(B, A);               //                        < 2.1p
+    const F Fm = fe_sub_nr<2>(D, C);           // D - C + 2p             < 4.2p
+    const F Gp = fe_add_nr(D, C);              //                        < 3.2p
+    F Fq = ed::select(neg, Gp, Fm);
+    F G = ed::select(neg, Fm, Gp);
+    e.X = fe_mul_io(E, Fq);                    // E and G are read again: handed back re-defined (field.hpp)
+    e.T = fe_mul(E, H);
+    e.Y = fe_mul_io(G, H);
+    e.Z = fe_mul(Fq, G);
 }
 BPP_HD Jac<Ed25519> xyzz_to_jac(const Xyzz<Ed25519>& p) { return p.e; }
 

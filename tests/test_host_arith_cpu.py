@@ -24,6 +24,11 @@ def test_lazy_mixed_addition_bounds_and_values():
     assert "ok bls12_381" in out and "ok secp256k1" in out
 
 
+def test_edwards_lazy_mixed_addition():
+    out = subprocess.check_output([_build("ed_lazy_host_test")]).decode()
+    assert "ok ed25519" in out
+
+
 def test_glv_split_matches_integers():
     exe = _build("glv_host_test", "-O2")
     r = P.BLS12_381["r"]
