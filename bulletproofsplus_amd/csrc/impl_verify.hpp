@@ -360,17 +360,22 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
     // Horner stage: one lane per proof, or -- while the waves are there to spare -- one wave per proof (tree); the tree
     // reads the window sums split by scalar half (k_var_windows)
-    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : 0u;
-    const size_t vlanes = count * (tree ? var_wsums<C>() : var_windows<C>());
+    // (mode 1, window sums split by scalar half); in between, eight lanes per proof (mode 2) while the launch would
+    // otherwise wait for the one-lane chains: the chain is ~2 ms, the eight-lane form costs ~0.09 us of chip time per
+    // proof on top of the fixed-generator work (~7 G mixed additions/s) -- measured on (64,1): better at 4 096 proofs,
+    // worse at 8 192
+    const bool small_job = (double)count * ((double)s.NF * s.W / 7.0e9 + 9.2e-8) < 2.0e-3;
+    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : (small_job ? 2u : 0u);
+    const size_t vlanes = count * (tree == 1 ? var_wsums<C>() : var_windows<C>());
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                        reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                       vlanes, tree);
+                       vlanes, tree == 1 ? 1u : 0u);
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
-    const unsigned hb = tree ? (unsigned)count : cdiv(count, FIXED_BLOCK);
+    const unsigned hb = tree == 1 ? (unsigned)count : cdiv(count, tree == 2 ? FIXED_BLOCK / 8 : FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
     launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree,
                            VpSel{1u, 0u, 1u, 0u});
@@ -383,7 +388,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
     hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
                        count * folded);
-    if (tree) {   // a small batch waits for latency, not throughput: one block per proof finishes the sum as a tree
+    if (tree == 1) {   // a small batch waits for latency, not throughput: one block per proof finishes the sum as a tree
         hipLaunchKernelGGL(k_finalize_tree<C>, dim3((unsigned)count), dim3(64), 0, st, w_fp, folded, w_vp, w_bad, d_ok,
                            reinterpret_cast<uint32_t*>(d_out_result), count);
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));

@@ -787,6 +787,49 @@ __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsu
     if (j == 0) jac_stg<C>(out + b * JW, acc);
 }
 
+// Between the two: EIGHT lanes per proof (eight proofs per wave), for batches that are too large for a wave per proof
+// but whose fixed-generator work is over before a one-lane chain would be (4 096 proofs of (64,1): the chain of 128
+// doublings + 33 additions was 2.2 of the pass's 3.7 ms).  Lane g runs Horner over its own eighth of the windows, then
+// three tree levels combine the eight partials: the same 128 (256) doublings on the critical path, 7 (11) additions.
+// Unsplit layout of the window sums (one per window).  Every lane of the wave must call it (`active`: has a proof).
+template <class C>
+__device__ __forceinline__ void var_horner_group(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
+                                                 bool active, uint32_t* lds_wave) {
+    constexpr uint32_t NW = var_windows<C>(), L = NW - 1, G = 8, CW = L / G;   // CW windows per lane + the carry window
+    static_assert(L % G == 0, "windows split evenly over the eight lanes");
+    constexpr int JW = jac_words<C>();
+    const uint32_t lane = threadIdx.x & 63u, g = lane & (G - 1);
+    Jac<C> acc = jac_inf<C>();
+    if (active) {
+        const int lo = (int)(g * CW);
+        const int top = g == G - 1 ? (int)L : lo + (int)CW - 1;
+        acc = var_wsum_ld<C, false>(wsum, b, (uint32_t)top);
+        for (int j = top - 1; j >= lo; j--) {
+            if (!acc.is_inf()) {
+                acc = jac_dbl(acc);
+                acc = jac_dbl(acc);
+                acc = jac_dbl(acc);
+                acc = jac_dbl(acc);
+            }
+            acc = jac_add(acc, var_wsum_ld<C, false>(wsum, b, (uint32_t)j));
+        }
+    }
+    for (uint32_t stride = 1; stride < G; stride <<= 1) {
+        jac_store(acc, lds_wave + (size_t)lane * JW);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active && (g & (2 * stride - 1)) == 0) {
+            Jac<C> hi = jac_load<C>(lds_wave + (size_t)(lane + stride) * JW);
+            if (!hi.is_inf())
+                for (uint32_t t = 0; t < 4 * CW * stride; t++) hi = jac_dbl(hi);
+            acc = jac_add(acc, hi);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (active && g == 0) jac_stg<C>(out + b * JW, acc);
+}
+
 // LDS-DMA (gfx950 global_load_lds_dwordx4): every lane copies 16 bytes from ITS OWN global address to
 // lds_byte_addr + lane * 16 (lds_byte_addr wave-uniform).  No VGPR destination, and -- being inline asm -- not
 // part of the compiler's s_waitcnt bookkeeping: the caller counts completions itself (vmcnt retires in order).
@@ -862,7 +905,10 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
     constexpr int WAVE_WORDS = (FIXED_RING * CH + 2) * 256;    // LDS words of one wave's ring + scalar buffer
     extern __shared__ __align__(16) uint32_t lds[];
     if (blockIdx.x < horner_blocks) {   // block-uniform: the Horner stage of the proof-point MSM
-        if (horner_tree) {   // small batches: one wave per proof, ONE proof per block (the block's second wave leaves):
+        if (horner_tree == 2) {   // mid-size batches: eight lanes per proof, blockDim.x / 8 proofs per block
+            const size_t b = (size_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+            var_horner_group<C>(wsum, var_out, b, b < horner_count, lds + (size_t)(threadIdx.x >> 6) * 64 * JW);
+        } else if (horner_tree) {   // small batches: one wave per proof, ONE proof per block (the block's second wave leaves):
                              // two tree waves in one block slowed each other down (5.8 ms for 2 proofs against 4.3 ms
                              // for one); a block per proof spreads the chains over the CUs
             const size_t b = blockIdx.x;
