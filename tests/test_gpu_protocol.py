@@ -333,6 +333,8 @@ def test_prove_batch_matches_oracle_small(cname, n, m, c):
     ("bls12_381", 16, 8, 4, 33),      # NF = 258 = 2 * 128 + 2: whole generators + left-over ones, 64 windows
     ("bls12_381", 32, 8, 11, 2500),   # NF = 514, one block per proof: 4 generators per lane + 2 spread
     ("ed25519", 8, 4, 6, 40),         # extended Edwards coordinates through the same kernels
+    ("ed25519", 8, 2, 5, 320),        # > 256 proofs of a small shape: the eight-lanes-per-proof Horner, 65 windows
+    ("bls12_381", 8, 2, 5, 300),      # ... and with the GLV split, 33 windows
 ])
 def test_shapes_and_batch_sizes_sweep(cname, n, m, c, count):
     """Launch geometry sweep of k_fixed_msm (lanes without generators, whole + left-over generators, one or several
