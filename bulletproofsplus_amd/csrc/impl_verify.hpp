@@ -199,7 +199,7 @@ struct VerifyImpl {
     };
     static size_t prove_chunk(const VerifyShape& s, size_t count) {
         const uint32_t nvp = pb_num_vps(s.k, s.m);
-        const size_t chunk_max = std::max<size_t>(1, std::min<size_t>(1024, ((size_t)6 << 30) / ((size_t)nvp * s.N * 32)));
+        const size_t chunk_max = std::max<size_t>(1, std::min<size_t>(2048, ((size_t)12 << 30) / ((size_t)nvp * s.N * 32)));
         return std::min(chunk_max, std::max<size_t>(count, 1));
     }
     static ProveLayout prove_layout(const VerifyShape& s, size_t count) {
