@@ -377,8 +377,10 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
     const unsigned hb = tree == 1 ? (unsigned)count : cdiv(count, tree == 2 ? FIXED_BLOCK / 8 : FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
-    launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count, tree,
-                           VpSel{1u, 0u, 1u, 0u});
+    // a launch whose blocks are all resident at once (<= 1024) also sums each block's partials itself (mode 3)
+    const bool lone = tree == 1 && count * bpp_ <= 1024;
+    launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count,
+                           lone ? 3u : tree, VpSel{1u, 0u, 1u, 0u});
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FINALIZE, st));
     // 128 per-thread partials per block -> 16 -> 4 (-> 4 per proof), every lane of the fold kernels busy;
@@ -386,15 +388,19 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const unsigned folded = bpp_ * (FIXED_BLOCK / FOLD_GROUP);
     const unsigned folded2 = folded / FOLD_GROUP2;
     uint32_t* w_fp2 = reinterpret_cast<uint32_t*>(ws + L.fpart2);
-    hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
-                       count * folded);
-    if (tree == 1) {   // a small batch waits for latency, not throughput: one block per proof finishes the sum as a tree
-        hipLaunchKernelGGL(k_finalize_tree<C>, dim3((unsigned)count), dim3(64), 0, st, w_fp, folded, w_vp, w_bad, d_ok,
-                           reinterpret_cast<uint32_t*>(d_out_result), count);
+    if (tree == 1) {   // a small batch waits for latency, not throughput: one block per proof finishes the sum as a tree,
+                       // over the per-block partials k_fixed_msm left (lone) or over the first fold pass's output
+        if (!lone)
+            hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
+                               count * folded);
+        hipLaunchKernelGGL(k_finalize_tree<C>, dim3((unsigned)count), dim3(64), 0, st, lone ? w_ft : w_fp,
+                           lone ? bpp_ : folded, w_vp, w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result), count);
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());
         return BPP_OK;
     }
+    hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
+                       count * folded);
     hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded2, 64)), dim3(64), 0, st, w_fp, FOLD_GROUP2, w_fp2,
                        count * folded2);
     const uint32_t* w_last = w_fp2;

@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
         if (horner_tree == 2) {   // mid-size batches: eight lanes per proof, blockDim.x / 8 proofs per block
             const size_t b = (size_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
             var_horner_group<C>(wsum, var_out, b, b < horner_count, lds + (size_t)(threadIdx.x >> 6) * 64 * JW);
-        } else if (horner_tree) {   // small batches: one wave per proof, ONE proof per block (the block's second wave leaves):
+        } else if (horner_tree) {   // (1 or 3) small batches: one wave per proof, ONE proof per block (the block's second wave leaves):
                              // two tree waves in one block slowed each other down (5.8 ms for 2 proofs against 4.3 ms
                              // for one); a block per proof spreads the chains over the CUs
             const size_t b = blockIdx.x;
@@ -1080,9 +1080,12 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
         if (valid) xyzz_madd_lazy(acc, cur, neg);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing dummy DMAs have landed: LDS may be reused
-    if (ROLE != 1) {
+    if (ROLE != 1 && horner_tree != 3) {
         // one partial per THREAD: a tree reduction here would run 7 jacobian additions with most lanes idle
-        // (~4.5 % of the block's time); k_partials_fold sums them with every lane busy
+        // (~4.5 % of the block's time); k_partials_fold sums them with every lane busy.  (Not for the small batches of
+        // the wave-tree mode: there the chip is mostly idle, the block's own tree runs beside the Horner chain that
+        // everything waits for anyway, and k_finalize_tree then has bpp_ partials per proof to add instead of 16 bpp_:
+        // horner_tree == 3, chosen while all the blocks of the launch are resident at once.)
         jac_stg<C>(partials + ((size_t)bid * blockDim.x + threadIdx.x) * JW, xyzz_to_jac(acc));
     } else {
         __syncthreads();
