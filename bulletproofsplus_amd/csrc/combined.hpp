@@ -11,7 +11,7 @@
 //     MulVec with scalars S_f = sum_p w_p * s_{p,f}               (k_comb_fixed, then k_fixed_msm, count 1)
 //   * the proof-carried points form ONE variable-base MulVec of B * (3+2k+m) terms with scalars
 //     w_p * s_{p,v} (k_comb_var_scalars).  It runs through the per-proof Straus kernels of the verifier
-//     (k_var_digits / k_var_tables / k_var_windows): the 65 window sums of every proof are added ACROSS proofs,
+//     (k_var_digits / k_var_tables / k_var_windows): the window sums of every proof (var_wsums) are added ACROSS proofs,
 //     window by window (k_comb_window_fold), and ONE Horner lane -- riding in the fixed-generator launch --
 //     finishes the sum.  (A 300 k-point bucket MSM took 17 ms per 8192 proofs here; this takes ~5 ms + the Horner.)
 // All-valid batches always pass; a batch with an invalid proof fails except with probability ~2^-128 PROVIDED the

@@ -93,7 +93,7 @@ struct VerifyImpl {
         w.vpart = o;
         o += al(count * JW * 4);                                   // one jacobian per proof
         w.vdig = o;
-        o += al(count * s.NV * VAR_DIGIT_STRIDE);                  // 65 digit bytes per proof point
+        o += al(count * s.NV * VAR_DIGIT_STRIDE);                  // digit bytes per proof point (65, or 2 x 33)
         w.vwsum = o;
         o += al(count * var_wsums<C>() * JW * 4);                     // window sums
         w.vtbl = o;

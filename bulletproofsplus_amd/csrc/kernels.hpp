@@ -1109,12 +1109,13 @@ __global__ void __launch_bounds__(64) k_partials_fold(const uint32_t* __restrict
 
 // ---- proof-dependent part: the 3 + 2k + m points carried by each proof / its commitments ---------------
 // Straus per proof, with the ~260 doublings paid once per proof and every addition a MIXED one:
-//   k_var_digits   one lane per (proof, point): 65 signed 4-bit digits of (scalar + 0x88..8), one byte each
+//   k_var_digits   one lane per (proof, point): the signed 4-bit digits of (scalar + 0x88..8), one byte each -- 65, or
+//                  2 x 33 after the GLV split of the scalar (BLS12-381)
 //   k_var_tables   one lane per (proof, point): the multiples 1P..8P as AFFINE points -- a chain of mixed
 //                  additions, then one inversion (safegcd) of the product of the seven Z's
 //   k_var_windows  one lane per (proof, window): sum over the proof's points of +-T[point][|digit|] in an XYZZ
 //                  accumulator (8M + 2S each, no bucket reduction)
-//   var_horner_lane  one lane per proof: Horner over the 65 window sums (4 doublings per step), run by the
+//   var_horner_lane / _group / _wave  Horner over the window sums (4 doublings per step), run by the
 //                  leading blocks of k_fixed_msm's grid
 
 // flat = 0: `scalars` is the verifier's [proof][N] array (the item's scalar sits at var_term_index);

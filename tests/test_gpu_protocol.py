@@ -529,7 +529,7 @@ def test_secp256k1_reference_size_against_oracle():
 
 def test_maximum_supported_shape_round_trip():
     """n = 64, m = 64 (mn = 4096, k = 12, 8 285 MulVec terms, 91 proof points): the largest shape the engine
-    accepts.  Exercises the > 64 KB dynamic-LDS path of k_verify_scalars and NV > 64 in the proof-point
+    accepts.  Exercises the > 64 KB dynamic-LDS path of k_vs_expand and NV > 64 in the proof-point
     kernels.  Round trip + tamper + combined check; shapes beyond the limit are usage errors."""
     torch = need_gpu()
     import bulletproofsplus_amd as B
