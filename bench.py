@@ -280,9 +280,13 @@ def main():
     backend = os.environ.get("BPP_BENCH_BACKEND", "nccl")
     if "BPP_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["BPP_BENCH_DEVICE"])
-    if world > 1:
+    # BPP_BENCH_FORCE_DIST=1 (not used by the driver): go through the process group and its collectives even as the only
+    # rank -- on a one-GPU box that is the way to have RCCL itself initialise and run the bench's all-reduce / all-gather
+    force_dist = os.environ.get("BPP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -751,7 +755,7 @@ def main():
                        "table_bytes": table_bytes_main, "parallelism": "proof-sharded x%d" % world,
                        "launcher": "bench.py spawned the ranks" if os.environ.get("BPP_BENCH_LAUNCHED") else
                                    ("external launcher" if world > 1 else "single process"),
-                       "backend": backend if world > 1 else None},
+                       "backend": backend if dist is not None else None},
             "roofline": {"bound": "alu", "kernel": "k_fixed_msm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": dom_ms, "launches_timed": passes,

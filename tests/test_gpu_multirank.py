@@ -51,6 +51,24 @@ def test_bench_spawns_two_ranks_c5_shape():
     assert line["cpu_baseline"] is None          # rank 0 at N = 1 only
 
 
+def test_rccl_initialises_and_runs_the_bench_collectives():
+    """One rank, backend nccl (= RCCL): the process group, the all-reduce of the verdict count and of `ranks_seen`, and the
+    all-gather of the combined-check partials all go through RCCL on the real device.  (Two RCCL ranks cannot share one
+    GPU; the N > 1 control flow is the gloo test above, the N > 1 RCCL run is the driver's.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "BPP_BENCH_BACKEND")}
+    env.update({"BPP_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port())})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--batch", "512", "--window", "10",
+           "--steps", "2", "--warmup", "1", "--combined-steps", "2", "--hard-steps", "0", "--other-curves-steps", "0",
+           "--prove-steps", "0", "--serialized-steps", "0", "--latency-steps", "0", "--cpu-seconds", "0", "--tampered", "5"]
+    out = subprocess.check_output(cmd, env=env, timeout=900)
+    line = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["config"]["backend"] == "nccl"
+    assert line["value"] > 0 and line["tamper_check"]["verdicts_exact"] is True and line["combined_check"]["value"] > 0
+
+
 def _worker(rank, world, port, tamper, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
