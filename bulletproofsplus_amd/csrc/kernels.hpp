@@ -69,7 +69,7 @@ constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P 
 #define BPP_VAR_WAVES 2
 #endif
 #ifndef BPP_VAR_TABLES_WAVES
-#define BPP_VAR_TABLES_WAVES 1
+#define BPP_VAR_TABLES_WAVES 2
 #endif
 
 // ---- small helpers -----------------------------------------------------------------------------------
@@ -615,19 +615,25 @@ __global__ void __launch_bounds__(64) k_transcript_challenges(VerifyShape s, Tra
 // each).  A Weierstrass point outside the prime-order subgroup (BLS12-381 G1 has cofactor 3 * 11^2 * ...) can
 // reach infinity inside the chain: such a point is parked as x = y = 0 with Z = 1, so the product stays
 // invertible and the scaled entry is the infinity encoding.  (Edwards: Z is never 0.)
+// `step` is given as a pointer (global memory) and re-read at every link, and the running product of the Z's lives in
+// `scratch` between links: both would otherwise sit in registers (39 of them for BLS12-381) across the mixed addition,
+// and with them the function does not fit the 256 registers of two waves per SIMD.
 template <class C>
-__device__ __forceinline__ void affine_chain(Jac<C> J, const Aff<C>& step, uint32_t count, uint32_t* __restrict__ out,
-                                             uint32_t* __restrict__ scratch) {
+__device__ __forceinline__ void affine_chain(Jac<C> J, const uint32_t* __restrict__ step_ptr, uint32_t count,
+                                             uint32_t* __restrict__ out, uint32_t* __restrict__ scratch) {
     using P = typename C::Fp;
     using F = Fe<P>;
     constexpr int N = P::N;
-    F run = F::one();
     uint32_t w[N];
     for (uint32_t k = 0; k < count; k++) {
-        if (k > 0) J = jac_madd(J, step);
+        if (k > 0) J = jac_madd(J, aff_ldg<C>(step_ptr));
         const bool at_inf = C::ID != 2 && J.is_inf();
         const F z = at_inf ? F::one() : J.Z;
-        run = fe_mul(run, z);
+        F run = z;
+        if (k > 0) {
+            ld_words<N>(scratch + (size_t)(count + k - 1) * N, w);
+            run = fe_mul(fe_load<P>(w), z);
+        }
         fe_store(at_inf ? F::zero() : J.X, w);
         st_words<N>(out + (size_t)k * 2 * N, w);
         fe_store(at_inf ? F::zero() : J.Y, w);
@@ -637,7 +643,8 @@ __device__ __forceinline__ void affine_chain(Jac<C> J, const Aff<C>& step, uint3
         fe_store(run, w);
         st_words<N>(scratch + (size_t)(count + k) * N, w);
     }
-    F inv = fe_inv(run);   // (Z_0 ... Z_{count-1})^-1
+    ld_words<N>(scratch + (size_t)(2 * count - 1) * N, w);
+    F inv = fe_inv(fe_load<P>(w));   // (Z_0 ... Z_{count-1})^-1
     for (uint32_t k = count; k-- > 0;) {
         F zi = inv;
         if (k > 0) {
@@ -684,9 +691,7 @@ __host__ __device__ __forceinline__ uint32_t tbl_runs_per_generator(const Verify
     return (s.W - 1) * ((s.half + TBL_RUN - 1) / TBL_RUN) + (s.top + TBL_RUN - 1) / TBL_RUN;
 }
 template <class C>
-// one wave per SIMD: the chain of mixed additions plus the safegcd inversion needs ~300 registers; at the two-wave
-// budget of 256 it spilled 220 bytes to scratch
-__global__ void __launch_bounds__(64, 1) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t* __restrict__ scratch,
+__global__ void __launch_bounds__(64, BPP_VAR_TABLES_WAVES) k_tbl_fill(VerifyShape s, uint32_t* __restrict__ table, uint32_t* __restrict__ scratch,
                                                     uint32_t f_begin, uint32_t f_end) {
     constexpr int N = C::Fp::N;
     const uint32_t runs_low = (s.half + TBL_RUN - 1) / TBL_RUN;
@@ -709,7 +714,7 @@ __global__ void __launch_bounds__(64, 1) k_tbl_fill(VerifyShape s, uint32_t* __r
         uint32_t kw[1] = {d0};
         J = aff_mul_words(base, kw, 1);
     }
-    affine_chain<C>(J, base, n, win + (size_t)(d0 - 1) * 2 * N, scratch + idx * 2 * TBL_RUN * N);
+    affine_chain<C>(J, win, n, win + (size_t)(d0 - 1) * 2 * N, scratch + idx * 2 * TBL_RUN * N);
 }
 
 // ---- the verification MulVec ---------------------------------------------------------------------------
@@ -1197,7 +1202,7 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_TABLES_WAVES) k_var_tables(
         for (int k = 1; k < M; k++) aff_stg<C>(T + (size_t)k * 2 * N, p);
         return;
     }
-    affine_chain<C>(aff_dbl(p), p, M - 1, T + 2 * N, S);   // 2P .. 8P
+    affine_chain<C>(aff_dbl(p), T, M - 1, T + 2 * N, S);   // 2P .. 8P (T[0] = P, stored above)
 }
 
 // split = 1: lane = (proof b, half h, window j), wsum[lane] = sum_v sign * T[b][v][|digit| - 1]   (half 1: of (beta x, -y))
