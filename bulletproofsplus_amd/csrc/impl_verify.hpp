@@ -95,7 +95,7 @@ struct VerifyImpl {
         w.vdig = o;
         o += al(count * s.NV * VAR_DIGIT_STRIDE);                  // digit bytes per proof point (65, or 2 x 33)
         w.vwsum = o;
-        o += al(count * var_wsums<C>() * JW * 4);                     // window sums
+        o += al(count * var_wsums_max<C>() * JW * 4);                 // window sums
         w.vtbl = o;
         o += al(count * s.NV * VAR_MULTIPLES * 2 * N * 4);         // 1P..8P of every proof point, affine
         w.vscr = o;
@@ -366,19 +366,21 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     // worse at 8 192
     const bool small_job = (double)count * ((double)s.NF * s.W / 7.0e9 + 9.2e-8) < 2.0e-3;
     const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : (small_job ? 2u : 0u);
-    const size_t vlanes = count * (tree == 1 ? var_wsums<C>() : var_windows<C>());
+    // a launch whose blocks are all resident at once (<= 1024): only latency counts -- its blocks also sum their own
+    // partials (mode 3 of k_fixed_msm) and the points of a proof are dealt to VAR_GROUPS lanes per window
+    const bool lone = tree == 1 && count * bpp_ <= 1024;
+    const uint32_t vgroups = lone ? VAR_GROUPS : 1u;
+    const size_t vlanes = count * (tree == 1 ? var_wsums<C>() * vgroups : var_windows<C>());
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                        reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                       vlanes, tree == 1 ? 1u : 0u);
+                       vlanes, tree == 1 ? 1u : 0u, vgroups);
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
     const unsigned hb = tree == 1 ? (unsigned)count : cdiv(count, tree == 2 ? FIXED_BLOCK / 8 : FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
-    // a launch whose blocks are all resident at once (<= 1024) also sums each block's partials itself (mode 3)
-    const bool lone = tree == 1 && count * bpp_ <= 1024;
     launch_fixed_msm<C, 0>((unsigned)(hb + count * bpp_), st, s, w_sc, v->table.u32(), w_ft, bpp_, hb, w_vw, w_vp, count,
                            lone ? 3u : tree, VpSel{1u, 0u, 1u, 0u});
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM + 1, st));
@@ -505,7 +507,7 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
     const size_t vlanes = count * var_wsums<C>();
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
-                       vlanes, 1u);
+                       vlanes, 1u, 1u);
     uint32_t* cur = w_vw;
     uint32_t* nxt = w_vf;
     for (size_t nrem = count; nrem > 1;) {

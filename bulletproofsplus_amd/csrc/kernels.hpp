@@ -59,6 +59,13 @@ template <class C>
 constexpr uint32_t var_wsums() {
     return var_windows<C>() * (var_glv<C>() ? 2u : 1u);
 }
+// ... and, for a launch so small that only latency counts (a lone proof), the proof's points are dealt to VAR_GROUPS
+// lanes per (half, window) as well: a third of the additions in a row, two more partial sums for the Horner wave to add
+constexpr uint32_t VAR_GROUPS = 3;
+template <class C>
+constexpr uint32_t var_wsums_max() {
+    return var_wsums<C>() * VAR_GROUPS;
+}
 constexpr uint32_t VAR_DIGIT_STRIDE = 80;  // bytes reserved per item in the digit buffer (16-byte multiple): 65, or 2 x 33
 constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P .. 8P
 // minimum waves per SIMD the register allocator must leave room for (512 VGPRs / waves)
@@ -726,12 +733,13 @@ __global__ void __launch_bounds__(64, BPP_VAR_TABLES_WAVES) k_tbl_fill(VerifySha
 // (one lane per proof; for small batches one wave per proof: var_horner_wave).
 // window sum j of proof b.  SPLIT (the layout k_var_windows writes for the tree Horner): S_j = (half 0) + (half 1)
 template <class C, bool SPLIT>
-__device__ __forceinline__ Jac<C> var_wsum_ld(const uint32_t* __restrict__ wsum, size_t b, uint32_t j) {
+__device__ __forceinline__ Jac<C> var_wsum_ld(const uint32_t* __restrict__ wsum, size_t b, uint32_t j, uint32_t groups = 1) {
     constexpr int JW = jac_words<C>();
     constexpr uint32_t NW = var_windows<C>();
-    const uint32_t* W = wsum + b * (SPLIT ? var_wsums<C>() : NW) * JW;
+    const uint32_t parts = SPLIT ? (var_wsums<C>() / NW) * groups : 1u;   // partial sums of window j: [group][half]
+    const uint32_t* W = wsum + b * parts * NW * JW;
     Jac<C> sj = jac_ldg<C>(W + (size_t)j * JW);
-    if constexpr (SPLIT && var_glv<C>()) sj = jac_add(sj, jac_ldg<C>(W + (size_t)(NW + j) * JW));
+    for (uint32_t t = 1; t < parts; t++) sj = jac_add(sj, jac_ldg<C>(W + (size_t)(t * NW + j) * JW));
     return sj;
 }
 
@@ -758,14 +766,14 @@ __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsu
 // additions of Horner's rule shrink to 7 on the critical path: ~2.4 ms instead of 3.5 ms.  `lds_wave`: 64 jacobians.
 template <class C>
 __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
-                                                uint32_t* lds_wave) {
+                                                uint32_t* lds_wave, uint32_t groups) {
     constexpr uint32_t NW = var_windows<C>(), L = NW - 1;   // L lanes + the carry window
     static_assert(L == 64 || L == 32, "a power of two of lanes within one wave");
     constexpr int JW = jac_words<C>();
     const uint32_t j = threadIdx.x & 63u;
-    Jac<C> acc = j < L ? var_wsum_ld<C, true>(wsum, b, j) : jac_inf<C>();
+    Jac<C> acc = j < L ? var_wsum_ld<C, true>(wsum, b, j, groups) : jac_inf<C>();
     if (j == L - 1) {   // the last window joins the slot before it: S_{L-1} + 16 * S_L
-        Jac<C> t = var_wsum_ld<C, true>(wsum, b, L);
+        Jac<C> t = var_wsum_ld<C, true>(wsum, b, L, groups);
         if (!t.is_inf()) {
             t = jac_dbl(t);
             t = jac_dbl(t);
@@ -917,7 +925,7 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
                              // two tree waves in one block slowed each other down (5.8 ms for 2 proofs against 4.3 ms
                              // for one); a block per proof spreads the chains over the CUs
             const size_t b = blockIdx.x;
-            if (b < horner_count && threadIdx.x < 64) var_horner_wave<C>(wsum, var_out, b, lds);
+            if (b < horner_count && threadIdx.x < 64) var_horner_wave<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
         } else {             // one lane per proof
             const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
             if (lane < horner_count) var_horner_lane<C>(wsum, var_out, lane);
@@ -1205,7 +1213,8 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_TABLES_WAVES) k_var_tables(
     affine_chain<C>(aff_dbl(p), T, M - 1, T + 2 * N, S);   // 2P .. 8P (T[0] = P, stored above)
 }
 
-// split = 1: lane = (proof b, half h, window j), wsum[lane] = sum_v sign * T[b][v][|digit| - 1]   (half 1: of (beta x, -y))
+// split = 1: lane = (proof b, group g of the points, half h, window j), wsum[lane] = sum_v sign * T[b][v][|digit| - 1]
+//            over the group's points (half 1: of (beta x, -y))
 //            -- the layout of the wave-tree Horner (small batches, the combined check), where nobody should wait for
 //            2 NV additions in a row;
 // split = 0: lane = (proof b, window j) adds both halves of every point itself, wsum holds var_windows sums per proof --
@@ -1214,7 +1223,7 @@ template <class C>
 __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(VerifyShape s, const uint8_t* __restrict__ digits,
                                                                          const uint32_t* __restrict__ tables,
                                                                          uint32_t* __restrict__ wsum, size_t lanes,
-                                                                         uint32_t split) {
+                                                                         uint32_t split, uint32_t groups) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1222,9 +1231,14 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
     constexpr uint32_t NW = var_windows<C>();
     constexpr uint32_t H = var_glv<C>() ? 2u : 1u;   // scalar halves per point (GLV: k1 on P, k2 on (beta x, -y))
     const uint32_t HL = split ? 1u : H;              // halves this lane adds
-    const size_t b = lane / (NW * (H / HL));
+    // split: lane = ((b * groups + g) * H + h) * NW + j ; else lane = b * NW + j (groups == 1)
+    const uint32_t per_proof = NW * (H / HL) * groups;
+    const size_t b = lane / per_proof;
+    const uint32_t g = (uint32_t)(lane % per_proof) / (NW * (H / HL));
     const uint32_t h0 = split ? (uint32_t)(lane / NW) % H : 0u;
     const uint32_t j = (uint32_t)(lane % NW);
+    const uint32_t gs = (s.NV + groups - 1) / groups;                  // points per group
+    const uint32_t v0 = g * gs, v1 = min(s.NV, v0 + gs);              // this lane's points
     const uint8_t* dg = digits + b * s.NV * VAR_DIGIT_STRIDE + j;   // half h's digits sit h * NW bytes further
     const uint32_t* T = tables + b * s.NV * VAR_MULTIPLES * 2 * N;
     Xyzz<C> acc = xyzz_inf<C>();
@@ -1235,15 +1249,15 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
     }
     // item u = (point u / HL, half h0 + u % HL); one entry in flight: the gather of item u + 1 is issued before the
     // addition of item u
-    const uint32_t items = s.NV * HL;
+    const uint32_t items = (v1 > v0 ? v1 - v0 : 0u) * HL;
     auto digit_of = [&](uint32_t u) -> int32_t {
-        return (int32_t)dg[(size_t)(u / HL) * VAR_DIGIT_STRIDE + (h0 + u % HL) * NW] - 8;
+        return (int32_t)dg[(size_t)(v0 + u / HL) * VAR_DIGIT_STRIDE + (h0 + u % HL) * NW] - 8;
     };
     auto entry_of = [&](uint32_t u, int32_t d) -> const uint32_t* {
-        return T + ((size_t)(u / HL) * VAR_MULTIPLES + (d < 0 ? -d : d) - 1) * 2 * N;
+        return T + ((size_t)(v0 + u / HL) * VAR_MULTIPLES + (d < 0 ? -d : d) - 1) * 2 * N;
     };
     uint32_t raw[2 * N];
-    int32_t d_next = digit_of(0);
+    int32_t d_next = items ? digit_of(0) : 0;
     if (d_next) ld_words<2 * N>(entry_of(0, d_next), raw);
     for (uint32_t u = 0; u < items; u++) {
         const int32_t d = d_next;
