@@ -25,8 +25,15 @@ struct bpp_verifier {
     std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x BPP_NUM_STAGES x 2
     size_t passes_recorded = 0;
     unsigned last_blocks_per_proof = 0;
+    // side stream of the lone-batch path (run(): the proof-point tables are built beside the verifier scalars), created
+    // on first use
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~bpp_verifier() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux) (void)hipStreamDestroy(aux);
     }
 };
 
@@ -345,6 +352,22 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
     HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
+    // Lone batches (below): the tables of the proof points need the points only, not the scalars -- a chain of seven
+    // additions and an inversion that nothing else waits for yet, so it runs on a side stream beside the (equally latency
+    // bound) scalar kernels and joins before the window sums.  Large batches fill the chip in every stage: one stream.
+    const bool side_tables = count * blocks_per_proof(s, count) <= 1024 && count <= HORNER_TREE_MAX;
+    if (side_tables) {
+        if (!v->aux) {
+            HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(v->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(v->aux, v->ev_fork, 0));
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, v->aux, w_pts, w_vt,
+                           reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
+        HIPCHK(hipEventRecord(v->ev_join, v->aux));
+    }
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     HIPCHK(mark(2 * BPP_STAGE_SCALARS, st));
@@ -373,8 +396,11 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const size_t vlanes = count * (tree == 1 ? var_wsums<C>() * vgroups : var_windows<C>());
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
-    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
-                       reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
+    if (side_tables)
+        HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
+    else
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
+                           reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes, tree == 1 ? 1u : 0u, vgroups);
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
