@@ -347,7 +347,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     }
     auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
     v->last_blocks_per_proof = bpp_;
-    HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
+    HIPCHK(zero_words_async(w_bad, count * 4, st));
     HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
@@ -460,7 +460,7 @@ int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, cons
     uint32_t* w_sc = reinterpret_cast<uint32_t*>(ws + L.scalars);
     uint32_t* w_st = reinterpret_cast<uint32_t*>(ws + L.status);
     uint64_t* w_ch = reinterpret_cast<uint64_t*>(ws + L.challenges);
-    HIPCHK(hipMemsetAsync(w_st, 0, count * 4, st));
+    HIPCHK(zero_words_async(w_st, count * 4, st));
     hipLaunchKernelGGL(k_container_decode<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, s, d_proofs, d_commitments,
                        w_rec, w_sc, w_st, count);
     HIPCHK(hipGetLastError());
@@ -508,8 +508,8 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     uint32_t* w_vw = reinterpret_cast<uint32_t*>(ws + L.vwsum);
     uint32_t* w_vf = reinterpret_cast<uint32_t*>(ws + L.vfold);
     const size_t items = count * s.NV;
-    HIPCHK(hipMemsetAsync(w_bad, 0, count * 4, st));
-    HIPCHK(hipMemsetAsync(w_cs, 0, (size_t)s.N * 32, st));
+    HIPCHK(zero_words_async(w_bad, count * 4, st));
+    HIPCHK(zero_words_async(w_cs, (size_t)s.N * 32, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();

@@ -81,6 +81,20 @@ constexpr uint32_t VAR_MULTIPLES = 8;      // table entries per proof point: 1P 
 
 // ---- small helpers -----------------------------------------------------------------------------------
 
+// Zero-fill as a kernel instead of hipMemsetAsync: inside a captured HIP graph (ROCm 7.2) the memset node of a fill of
+// more than ~1 KB wrote garbage from its second replay on (tests/test_gpu_round2.py::test_verifier_run_is_graph_capturable
+// found every proof of a 300-proof batch "invalid" that way); a kernel node replays as it was captured.
+static __global__ void __launch_bounds__(256) k_zero_words(uint32_t* __restrict__ p, size_t words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) p[i] = 0;
+}
+inline hipError_t zero_words_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t words = (bytes + 3) / 4;
+    if (words == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(p), words);
+    return hipGetLastError();
+}
+
 template <int NW>
 __device__ __forceinline__ void ld_words(const uint32_t* __restrict__ p, uint32_t* dst) {
     static_assert(NW % 4 == 0, "16-byte granules");

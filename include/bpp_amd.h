@@ -153,6 +153,9 @@ size_t bpp_verifier_table_bytes(const bpp_verifier *v);
  *   d_out_scalars: count x N scalars -- the MulVec scalars in the reference's MulVec order
  *                  (range/mod.rs:481-490 for m > 1, wip.rs:298-307 for m == 1)
  *   d_out_result : count x wire point -- the MulVec result ("expected", range/mod.rs:503)
+ * The call only enqueues work on `stream` (kernels, and for a batch small enough to be latency bound an event fork/join
+ * with a side stream of the verifier): after one eager call it can be captured into a HIP graph and replayed
+ * (tests/test_gpu_round2.py::test_verifier_run_is_graph_capturable).
  * Points are elements of the prime-order group (what the prover, mcl, or the decoder with its subgroup check produce).
  * On BLS12-381 the proof-carried points are multiplied through G1's endomorphism (GLV, as mcl itself does): for points
  * of G1 the result is sum s_i P_i bit for bit; a curve point OUTSIDE G1 is still processed deterministically and its

@@ -393,3 +393,46 @@ def test_wip_fold_round_seam(cname):
     with pytest.raises(B.BppError):
         B.wip_fold_round(a, av[:6], bv_[:6], O.points_to_wire(cid, list(pk.G_vec[:6])), O.points_to_wire(cid, list(pk.H_vec[:6])),
                          y_nhat, e)
+
+
+@pytest.mark.parametrize("count", [1, 5, 300])
+def test_verifier_run_is_graph_capturable(count):
+    """bpp_verifier_run only enqueues work (memsets, launches, and for a lone batch an event fork/join with its side
+    stream): after one eager call it can be captured into a HIP graph; a replay gives the verdicts of the eager pass,
+    including after the inputs in the captured buffers change."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    n, m = 8, 2
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=5)
+    recs, scs, _, _ = _prove_batch(bv, count, m, nbits=n)
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(recs.view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(scs.view(np.int64)).to(dev)
+    d_ok = torch.full((count,), 7, dtype=torch.int32, device=dev)
+    wsb = bv.workspace_bytes(count)
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()          # the uploads above ran on the default stream; `s` does not wait for it by itself
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        bv.run_device(d_pts.data_ptr(), d_sc.data_ptr(), count, d_ok.data_ptr(), d_ws.data_ptr(), wsb, s.cuda_stream)
+        s.synchronize()
+    assert d_ok.cpu().numpy().tolist() == [0] * count
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        bv.run_device(d_pts.data_ptr(), d_sc.data_ptr(), count, d_ok.data_ptr(), d_ws.data_ptr(), wsb,
+                      torch.cuda.current_stream().cuda_stream)
+    d_ok.fill_(7)
+    g.replay()
+    torch.cuda.synchronize()
+    assert d_ok.cpu().numpy().tolist() == [0] * count
+    bad = scs.copy()
+    bad[count // 2, 1, 0] ^= np.uint64(2)
+    d_sc.copy_(torch.from_numpy(bad.view(np.int64)))
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    assert d_ok.cpu().numpy().tolist() == [1 if i == count // 2 else 0 for i in range(count)]
+    del g
+    bv.close()
