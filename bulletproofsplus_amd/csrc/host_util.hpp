@@ -114,7 +114,7 @@ int upload_points(const uint64_t* wire, size_t n, DevBuf& affm, hipStream_t st) 
     HIPCHK(dw.alloc(n * wire_words<C>() * 4));
     HIPCHK(bad.alloc(4));
     HIPCHK(affm.alloc(n * 2 * N * 4));
-    HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
+    HIPCHK(zero_words_async(bad.p, 4, st));
     if (n) {
         HIPCHK(hipMemcpyAsync(dw.p, wire, n * wire_words<C>() * 4, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(n, 128)), dim3(128), 0, st, dw.u32(), affm.u32(),

@@ -355,9 +355,9 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     uint32_t* hlist = reinterpret_cast<uint32_t*>(d_ws + w.hlist);
     uint32_t* hcount = reinterpret_cast<uint32_t*>(d_ws + w.hcount);
     uint32_t* hparts = reinterpret_cast<uint32_t*>(d_ws + w.hparts);
-    hipError_t e = hipMemsetAsync(counts, 0, (size_t)s.W * s.half * 4, st);
+    hipError_t e = zero_words_async(counts, (size_t)s.W * s.half * 4, st);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(hcount, 0, 4, st);
+    e = zero_words_async(hcount, 4, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pip_digits<C>, dim3((s.n + 255) / 256), dim3(256), 0, st, s, d_scalars, keys, slots, counts);
     hipLaunchKernelGGL(k_pip_scan<C>, dim3(s.W), dim3(1024), 0, st, s, counts, offsets);
