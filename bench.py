@@ -691,13 +691,14 @@ def main():
     # ---- secondary, separately timed: the same shape on the other instantiations of the same kernel templates.
     # BASELINE.json's configs[1] names Ristretto; the reference has no such backend, so the
     # edwards25519 instantiation is parity-unpinned and can never be the headline; secp256k1 is the reference's
-    # second in-tree backend.  Window 16 for both (65 / 73 GB of tables).
+    # second in-tree backend.  Windows 17 / 16 (123 / 73 GB of tables).
     others = None
     if args.other_curves_steps > 0 and args.curve == "bls12_381":
         others = {}
         release_main()
         for oc in ("ed25519", "secp256k1"):
-            others[oc] = side_leg(oc, n, m, Bsz, 16, args.other_curves_steps)
+            # 253-bit group order: 15 windows at c = 17 against 16 at c = 16 (123 GB of tables); 256 bits need 16 either way
+            others[oc] = side_leg(oc, n, m, Bsz, 17 if oc == "ed25519" else 16, args.other_curves_steps)
             others[oc]["parity"] = ("unpinned: not a reference backend; the prime-order subgroup of the curve under Ristretto255"
                                     if oc == "ed25519" else "the reference's second in-tree backend (not wired to its range proof)")
 
