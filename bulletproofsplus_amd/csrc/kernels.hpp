@@ -921,6 +921,10 @@ template <class C>
 constexpr int fixed_waves() {
     return C::Fp::NL > 9 ? BPP_FIXED_WAVES : 3;
 }
+// horner_tree (the form of the Horner stage in the leading `horner_blocks` blocks; chosen on the host, impl_verify.hpp):
+//   0  one lane per proof (large batches)            2  eight lanes per proof (mid-size batches)
+//   1  one wave per proof, window sums split by half 3  as 1, with the proof's points in VAR_GROUPS groups, and every
+//                                                        block of the launch sums its own partials (lone batches)
 template <class C, int ROLE = 0>
 __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(VerifyShape s, const uint32_t* __restrict__ scalars,
                             const uint32_t* __restrict__ table, uint32_t* __restrict__ partials, uint32_t per,
