@@ -154,6 +154,18 @@ def msm_pippenger(arith: Arith, scalars, points, window_bits: int = 0) -> np.nda
     return out
 
 
+def msm_workspace_bytes(arith: Arith, n: int, window_bits: int = 0) -> int:
+    return _lib.lib().bpp_msm_workspace_bytes(arith.handle, n, window_bits)
+
+
+def msm_device(arith: Arith, d_scalars: int, d_points: int, n: int, d_out: int, d_workspace: int, workspace_bytes: int,
+               window_bits: int = 0, d_status: int = 0, stream: int = 0):
+    """MulVec::calculate with every buffer in HBM (raw device pointers, e.g. torch tensors' data_ptr()), asynchronous
+    on `stream`: d_scalars (n, 4) u64, d_points (n, PW) u64 wire points, d_out one wire point, d_status one u32."""
+    check(_lib.lib().bpp_msm_device(arith.handle, d_scalars or None, d_points or None, n, window_bits, d_out,
+                                    d_status or None, d_workspace, workspace_bytes, stream or None), "bpp_msm_device")
+
+
 def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
     """`len(lens)` independent MulVecs in one launch."""
     sc = scalars_to_wire(scalars)

@@ -56,6 +56,29 @@ extern "C" int bpp_msm_pippenger(bpp_ctx* ctx, const uint64_t* scalars, const ui
     });
 }
 
+extern "C" size_t bpp_msm_workspace_bytes(bpp_ctx* ctx, size_t n, int window_bits) {
+    if (!ctx) return 0;
+    size_t r = 0;
+    dispatch(ctx->curve, [&](auto cv) -> int {
+        r = MsmImpl<decltype(cv)>::msm_workspace_bytes(n, window_bits);
+        return 0;
+    });
+    return r;
+}
+
+extern "C" int bpp_msm_device(bpp_ctx* ctx, const uint64_t* d_scalars, const uint64_t* d_points, size_t n, int window_bits,
+                              uint64_t* d_out, uint32_t* d_status, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !d_out || !d_workspace || (n && (!d_scalars || !d_points))) return fail(BPP_E_ARG, "null argument");
+    if (window_bits && (window_bits < 2 || window_bits > 16)) return fail(BPP_E_ARG, "window_bits must be in [2, 16]");
+    HIPCHK(hipSetDevice(ctx->device));
+    return dispatch(ctx->curve, [&](auto cv) -> int {
+        return MsmImpl<decltype(cv)>::msm_device(reinterpret_cast<const uint32_t*>(d_scalars),
+                                                 reinterpret_cast<const uint32_t*>(d_points), n, window_bits,
+                                                 reinterpret_cast<uint32_t*>(d_out), d_status, d_workspace, workspace_bytes,
+                                                 static_cast<hipStream_t>(stream));
+    });
+}
+
 extern "C" int bpp_scalar_mul_batch(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n,
                                     uint64_t* out) {
     if (!ctx || !out || (n && (!scalars || !points))) return fail(BPP_E_ARG, "null argument");

@@ -74,12 +74,15 @@ struct MsmImpl {
     static int msm_batch_dev(const uint32_t* d_scalars, const uint32_t* d_points, const std::vector<uint64_t>& offsets,
                              uint64_t* out, hipStream_t st);
 
-    // one large MulVec through the bucket method (pippenger.hpp); window_bits = 0 picks it from n
+    // one large MulVec through the bucket method (pippenger.hpp), every buffer in HBM, asynchronous on `st`:
+    // d_scalars n canonical scalars, d_wire_points n wire points, d_out_wire one wire point, d_status (may be null) one
+    // word: 1 when a point was invalid.  window_bits = 0 picks the width from n.
     static constexpr size_t PIPPENGER_MIN_N = 4096;
-    static int msm_pippenger_dev(const uint32_t* d_scalars, const uint32_t* d_points, size_t n, int window_bits,
-                                 uint64_t* out, hipStream_t st);
+    static size_t msm_workspace_bytes(size_t n, int window_bits);
+    static int msm_device(const uint32_t* d_scalars, const uint32_t* d_wire_points, size_t n, int window_bits,
+                          uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st);
 
-    // explicit window width (tests sweep it); host pointers
+    // the same from host pointers (uploads, runs, downloads); explicit window width (tests sweep it)
     static int msm_pippenger(const uint64_t* scalars, const uint64_t* points, size_t n, int window_bits, uint64_t* out);
 
     static int msm_batch(const uint64_t* scalars, const uint64_t* points, const uint32_t* lens, size_t count,
@@ -116,9 +119,6 @@ int MsmImpl<C>::msm_batch_dev(const uint32_t* d_scalars, const uint32_t* d_point
                          uint64_t* out, hipStream_t st) {
     const size_t count = offsets.size() - 1;
     if (count == 0) return BPP_OK;
-    if (count == 1 && offsets[1] - offsets[0] >= PIPPENGER_MIN_N)
-        return msm_pippenger_dev(d_scalars + offsets[0] * 8, d_points + offsets[0] * 2 * N, offsets[1] - offsets[0],
-                                 0, out, st);
     size_t maxlen = 0;
     for (size_t c = 0; c < count; c++) maxlen = std::max<size_t>(maxlen, offsets[c + 1] - offsets[c]);
     const unsigned block = MSM_BLOCK;
@@ -139,20 +139,29 @@ int MsmImpl<C>::msm_batch_dev(const uint32_t* d_scalars, const uint32_t* d_point
 }
 
 template <class C>
-int MsmImpl<C>::msm_pippenger_dev(const uint32_t* d_scalars, const uint32_t* d_points, size_t n, int window_bits,
-                             uint64_t* out, hipStream_t st) {
-    if (n >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "n too large");
-    const PipShape ps = pip_shape(n, window_bits ? window_bits : pip_pick_c(n));
-    const PipWorkspace pw = pip_workspace<C>(ps);
-    DevBuf ws, res, dout;
-    HIPCHK(ws.alloc(pw.total));
-    HIPCHK(res.alloc(JW * 4));
-    HIPCHK(dout.alloc(WW * 4));
-    HIPCHK(pip_launch<C>(ps, d_scalars, d_points, static_cast<uint8_t*>(ws.p), nullptr, 0, res.u32(), st));
-    hipLaunchKernelGGL(k_jac_reduce<C>, dim3(1), dim3(64), 0, st, res.u32(), 1u, dout.u32(), (size_t)1);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, dout.p, WW * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+size_t MsmImpl<C>::msm_workspace_bytes(size_t n, int window_bits) {
+    if (n == 0) return 256;
+    if (n >= ((size_t)1 << 28)) return 0;
+    PipShape ps;
+    if (pip_shape_for<C>(n, window_bits ? window_bits : pip_pick_c<C>(n), ps)) return 0;
+    return pip_workspace<C>(ps).total;
+}
+
+template <class C>
+int MsmImpl<C>::msm_device(const uint32_t* d_scalars, const uint32_t* d_wire_points, size_t n, int window_bits,
+                           uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st) {
+    if (n >= ((size_t)1 << 28)) return fail(BPP_E_ARG, "n too large");
+    if (n == 0) {   // Point::zero()
+        if (d_status) HIPCHK(zero_words_async(d_status, 4, st));
+        hipLaunchKernelGGL(k_pip_zero_point<C>, dim3(1), dim3(64), 0, st, d_out_wire);
+        HIPCHK(hipGetLastError());
+        return BPP_OK;
+    }
+    PipShape ps;
+    int rc = pip_shape_for<C>(n, window_bits ? window_bits : pip_pick_c<C>(n), ps);
+    if (rc) return rc;
+    if (ws_bytes < pip_workspace<C>(ps).total) return fail(BPP_E_ARG, "workspace too small (bpp_msm_workspace_bytes)");
+    HIPCHK(pip_launch<C>(ps, d_scalars, d_wire_points, static_cast<uint8_t*>(d_ws), d_out_wire, d_status, st));
     return BPP_OK;
 }
 
@@ -164,12 +173,23 @@ int MsmImpl<C>::msm_pippenger(const uint64_t* scalars, const uint64_t* points, s
         out[PW - 1] = 1;
         return BPP_OK;
     }
-    DevBuf dsc, dpt;
-    int rc = upload_scalars<C>(scalars, n, dsc, nullptr);
+    const size_t wsb = msm_workspace_bytes(n, window_bits);
+    if (wsb == 0) return fail(BPP_E_ARG, "n too large");
+    DevBuf dsc, dpt, ws, dout, dst;
+    HIPCHK(dsc.alloc(n * 32));
+    HIPCHK(dpt.alloc(n * WW * 4));
+    HIPCHK(ws.alloc(wsb));
+    HIPCHK(dout.alloc(WW * 4));
+    HIPCHK(dst.alloc(4));
+    HIPCHK(hipMemcpy(dsc.p, scalars, n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dpt.p, points, n * WW * 4, hipMemcpyHostToDevice));
+    int rc = msm_device(dsc.u32(), dpt.u32(), n, window_bits, dout.u32(), dst.u32(), ws.p, wsb, nullptr);
     if (rc) return rc;
-    rc = upload_points<C>(points, n, dpt, nullptr);
-    if (rc) return rc;
-    return msm_pippenger_dev(dsc.u32(), dpt.u32(), n, window_bits, out, nullptr);
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpy(out, dout.p, WW * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&bad, dst.p, 4, hipMemcpyDeviceToHost));
+    if (bad) return fail(BPP_E_POINT, "point not on curve / coordinate out of range");
+    return BPP_OK;
 }
 
 template <class C>
@@ -179,6 +199,7 @@ int MsmImpl<C>::msm_batch(const uint64_t* scalars, const uint64_t* points, const
     for (size_t c = 0; c < count; c++) off[c + 1] = off[c] + lens[c];
     const size_t total = off[count];
     if (total && (!scalars || !points)) return fail(BPP_E_ARG, "null scalars/points");
+    if (count == 1 && total >= PIPPENGER_MIN_N) return msm_pippenger(scalars, points, total, 0, out);
     DevBuf dsc, dpt;
     int rc = upload_scalars<C>(scalars, total, dsc, nullptr);
     if (rc) return rc;

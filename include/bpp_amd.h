@@ -72,6 +72,23 @@ int bpp_msm(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_
 int bpp_msm_pippenger(bpp_ctx *ctx, const uint64_t *scalars, const uint64_t *points, size_t n, int window_bits,
                       uint64_t *out);
 
+/* MulVec::calculate (mulvec.rs:20-33) with EVERY buffer in HBM, asynchronous on `stream` (a hipStream_t; NULL = default
+ * stream): nothing is copied, nothing synchronises -- the seam for callers whose scalars and points already live on
+ * the device, and what bench.py's `msm` leg times.  The bucket (Pippenger) pipeline of csrc/pippenger.hpp at any n:
+ * signed c-bit windows with an unsigned top window, on BLS12-381 after the GLV split of every scalar (two 128-bit halves
+ * per point), counting sort per window, one lane per bucket with an LDS-DMA gather ring, bucket sums reduced per tile
+ * of 64 S buckets by one wave (running sums per lane, suffix scan and butterfly across the wave by shuffles).
+ *   d_scalars : n scalars (4 x u64, canonical; values >= r are reduced on the device)
+ *   d_points  : n wire points
+ *   d_out     : one wire point (affine, canonical) -- the sum, bit for bit what bpp_msm returns
+ *   d_status  : one uint32_t (may be NULL): 0, or 1 when some point was not on the curve / had a coordinate >= p (the
+ *               host-pointer calls report BPP_E_POINT; here the point counts as infinity and the flag is raised)
+ *   d_workspace: bpp_msm_workspace_bytes(ctx, n, window_bits) bytes
+ * window_bits in [2, 16], 0 = chosen from n.  n == 0 gives Point::zero(). */
+size_t bpp_msm_workspace_bytes(bpp_ctx *ctx, size_t n, int window_bits);
+int bpp_msm_device(bpp_ctx *ctx, const uint64_t *d_scalars, const uint64_t *d_points, size_t n, int window_bits,
+                   uint64_t *d_out, uint32_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* `count` independent MulVecs in one launch: MulVec c has lens[c] terms starting at offset
  * sum(lens[0..c)).  out: count points.  (The fold of src/weighted_inner_product_proof.rs:151-163 is
  * 2 n' MulVecs of length 2.)  Host pointers. */
