@@ -52,6 +52,11 @@ CONFIGS = {
 }
 
 
+MSM_ORDER = {"bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001,
+             "secp256k1": 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+             "ed25519": (1 << 252) + 27742317777372353535851937790883648493}
+
+
 def synth_values(seed, m):
     """v_j = (0x9E3779B97F4A7C15 * (j+1+seed)) mod 2^31 (< 2^31 because of prover.rs:37), gamma_j = j+3+seed"""
     vals = [((0x9E3779B97F4A7C15 * (j + 1 + seed)) & 0xFFFFFFFFFFFFFFFF) % (1 << 31) for j in range(m)]
@@ -258,6 +263,9 @@ def main():
     ap.add_argument("--prove-steps", type=int, default=2, help="steps of the device-resident batched prover leg; 0 = skip")
     ap.add_argument("--serialized-steps", type=int, default=3,
                     help="steps of the serialized-input leg (containers + compressed commitments resident in HBM); 0 = skip")
+    ap.add_argument("--msm-steps", type=int, default=5,
+                    help="steps per point of the `msm` leg (device-resident general MulVec, N = 2^16 .. 2^22 on the three curves); 0 = skip")
+    ap.add_argument("--msm-log2n", type=int, nargs="+", default=[16, 18, 20, 22])
     ap.add_argument("--tampered", type=int, default=64, help="tampered proofs of the untimed verdict check after the timed region")
     ap.add_argument("--dry-run", action="store_true", help="launcher/collective rehearsal without a GPU (see dry_run)")
     args = ap.parse_args()
@@ -702,6 +710,84 @@ def main():
             others[oc]["parity"] = ("unpinned: not a reference backend; the prime-order subgroup of the curve under Ristretto255"
                                     if oc == "ed25519" else "the reference's second in-tree backend (not wired to its range proof)")
 
+    # ---- secondary, separately timed: MulVec::calculate as a seam of its own at large N (bpp_msm_device) ---------
+    # scalars and points resident in HBM, full-width scalars, distinct points k_i g (made on the GPU); every size is
+    # checked against the known discrete logs: sum_i s_i (k_i g) == (sum_i s_i k_i) g.
+    msm = None
+    if args.msm_steps > 0 and args.curve == "bls12_381":
+        release_main()
+        msm = {"unit": "points/s", "steps": args.msm_steps,
+               "workload": "one MulVec of N full-width scalars x N distinct points, all in HBM; result checked against the points' discrete logs",
+               "curves": {}}
+        try:
+            uj = json.load(open(os.path.join(ROOT, "profiles", "ubench_r02.json")))
+        except Exception:
+            uj = {}
+        for mc in ("bls12_381", "secp256k1", "ed25519"):
+            a_m = B.Arith.init(mc, local_rank)
+            order = MSM_ORDER[mc]
+            g_m = B.PublicKey.new(a_m, 0).gh[0]
+            fpb = (a_m.PW - 1) // 2 * 8
+            loop_peak = (uj.get({"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}.get(mc, "")) or {}).get("Gops")
+            rows = []
+            for lg in args.msm_log2n:
+                N = 1 << lg
+                rng = np.random.RandomState(1000 * rank + lg)
+                ks = rng.randint(1, 2**62, size=N).astype(np.uint64)
+                kw = np.zeros((N, 4), dtype=np.uint64)
+                kw[:, 0] = ks
+                pts_m = np.zeros((N, a_m.PW), dtype=np.uint64)
+                for lo in range(0, N, 1 << 18):
+                    hi = min(N, lo + (1 << 18))
+                    pts_m[lo:hi] = a_m.scalar_mul(kw[lo:hi], np.broadcast_to(g_m, (hi - lo, a_m.PW)).copy())
+                sc_m = rng.randint(0, 2**63 - 1, size=(N, 4)).astype(np.uint64) * np.uint64(2) + rng.randint(0, 2, size=(N, 4)).astype(np.uint64)
+                sc_m[:, 3] >>= np.uint64(4)                   # < 2^252: below every curve's group order
+                so = sc_m[:, 0].astype(object) + (sc_m[:, 1].astype(object) << 64) + (sc_m[:, 2].astype(object) << 128) + (sc_m[:, 3].astype(object) << 192)
+                tot = int((so * ks.astype(object)).sum() % order)
+                exp = a_m.scalar_mul(np.array([[(tot >> (64 * t)) & 0xFFFFFFFFFFFFFFFF for t in range(4)]], dtype=np.uint64), g_m[None])[0]
+                d_sc_m = torch.from_numpy(sc_m.view(np.int64)).to(dev)
+                d_pt_m = torch.from_numpy(pts_m.view(np.int64)).to(dev)
+                d_out_m = torch.zeros(a_m.PW, dtype=torch.int64, device=dev)
+                d_st_m = torch.full((1,), 7, dtype=torch.int32, device=dev)
+                wsb_m = B.msm_workspace_bytes(a_m, N, 0)
+                d_ws_m = torch.empty(wsb_m, dtype=torch.uint8, device=dev)
+
+                def mstep(_i):
+                    B.msm_device(a_m, d_sc_m.data_ptr(), d_pt_m.data_ptr(), N, d_out_m.data_ptr(), d_ws_m.data_ptr(), wsb_m,
+                                 window_bits=0, d_status=d_st_m.data_ptr(), stream=stream)
+                mstep(0)
+                torch.cuda.synchronize()
+                assert int(d_st_m.item()) == 0
+                assert np.array_equal(d_out_m.cpu().numpy().view(np.uint64), exp), "msm leg: wrong sum at %s N=2^%d" % (mc, lg)
+                B.msm_set_profiling(a_m, True)
+                mdt = timed(mstep, args.msm_steps, torch, dist, coll_dev)
+                mst, mpasses, mshape = B.msm_profile(a_m)
+                B.msm_set_profiling(a_m, False)
+                ms_call = mdt / args.msm_steps * 1e3
+                alg = N * (2 * fpb + 32)                      # one affine point + one scalar per term
+                madds = mshape["windows"] * mshape["items"]   # one bucket addition per (item, window); zero digits (2^-w of them) skipped
+                kern_ms = sum(mst.values())
+                add_rate = madds / (mst["chunks"] * 1e-3) / 1e9 if mst["chunks"] > 0 else 0.0
+                rows.append({"log2n": lg, "ms": ms_call, "value": world * N / (ms_call * 1e-3),
+                             "stage_ms": {k: round(v, 4) for k, v in mst.items()}, "shape": mshape,
+                             "workspace_bytes": wsb_m,
+                             "roofline": {"bound": "hbm", "limiter": "alu", "kernel": "k_pip_* (all stages of one call)",
+                                          "algorithmic_bytes": alg, "kernel_ms": kern_ms,
+                                          "achieved": alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
+                                          "traffic": None,
+                                          "alu": {"unit": "G mixed additions/s", "kernel": "k_pip_chunks", "additions": madds,
+                                                  "additions_per_point": madds / N, "achieved": add_rate, "peak": loop_peak,
+                                                  "frac": (add_rate / loop_peak) if loop_peak else None,
+                                                  "whole_call_frac": (madds / (ms_call * 1e-3) / 1e9 / loop_peak) if loop_peak else None}}})
+                del d_ws_m, d_sc_m, d_pt_m
+                torch.cuda.empty_cache()
+            msm["curves"][mc] = rows
+        msm["value"] = msm["curves"]["bls12_381"][-1]["value"]
+        msm["note"] = ("value = the largest BLS12-381 point; roofline.achieved = N x (affine point + scalar) bytes / the summed stage "
+                       "time of one call (HIP events on the launch stream) -- integer-ALU bound like the verifier; alu = bucket additions "
+                       "per second of k_pip_chunks against the register-resident loop of the same addition (profiles/ubench_r02.json)")
+
     if rank == 0:
         N_msm = msm_len_main
         NF = 2 * n * m + 2
@@ -784,6 +870,7 @@ def main():
             "c3": c3,
             "hard_distribution": hard,
             "other_curves": others,
+            "msm": msm,
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},
         }
         if args.cpu_seconds > 0 and world == 1 and args.curve != "ed25519":   # the C oracle has no Edwards backend

@@ -27,7 +27,7 @@ FORMAT_ERROR = 2   # ProofError::FormatError (reference src/errors.rs:20)
 # every symbol include/bpp_amd.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "bpp_init", "bpp_destroy", "bpp_last_error", "bpp_point_words", "bpp_msm", "bpp_msm_batch", "bpp_msm_pippenger",
-    "bpp_msm_workspace_bytes", "bpp_msm_device",
+    "bpp_msm_workspace_bytes", "bpp_msm_device", "bpp_msm_set_profiling", "bpp_msm_profile",
     "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_pk_hashed", "bpp_commit", "bpp_range_prove", "bpp_range_prove_batch", "bpp_range_verify", "bpp_wip_fold_round",
     "bpp_prover_workspace_bytes", "bpp_range_prove_batch_device",
     "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
@@ -73,6 +73,8 @@ def lib():
         L.bpp_msm_workspace_bytes.argtypes = [vp, sz, i32]
         L.bpp_msm_workspace_bytes.restype = sz
         L.bpp_msm_device.argtypes = [vp, vp, vp, sz, i32, vp, vp, vp, sz, vp]
+        L.bpp_msm_set_profiling.argtypes = [vp, i32]
+        L.bpp_msm_profile.argtypes = [vp, vp, vp, vp]
         L.bpp_scalar_mul_batch.argtypes = [vp, vp, vp, sz, vp]
         L.bpp_pk_new.argtypes = [vp, sz, vp, vp, vp]
         L.bpp_pk_hashed.argtypes = [vp, ctypes.c_char_p, sz, sz, vp, vp, vp]

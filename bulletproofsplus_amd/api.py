@@ -166,6 +166,23 @@ def msm_device(arith: Arith, d_scalars: int, d_points: int, n: int, d_out: int, 
                                     d_status or None, d_workspace, workspace_bytes, stream or None), "bpp_msm_device")
 
 
+MSM_STAGES = ("sort", "chunks", "fold", "reduce", "final")
+
+
+def msm_set_profiling(arith: Arith, on: bool):
+    check(_lib.lib().bpp_msm_set_profiling(arith.handle, 1 if on else 0), "bpp_msm_set_profiling")
+
+
+def msm_profile(arith: Arith):
+    """-> ({stage: mean ms}, passes, shape dict of the last bpp_msm_device call), HIP events on the launch stream"""
+    ms = (ctypes.c_float * 5)()
+    passes = ctypes.c_size_t()
+    sh = (ctypes.c_uint32 * 8)()
+    check(_lib.lib().bpp_msm_profile(arith.handle, ms, ctypes.byref(passes), sh), "bpp_msm_profile")
+    keys = ("n", "items", "windows", "narrow_bits", "wide_windows", "buckets", "chunk_entries", "window_bits")
+    return {k: float(ms[i]) for i, k in enumerate(MSM_STAGES)}, passes.value, {k: int(sh[i]) for i, k in enumerate(keys)}
+
+
 def msm_batch(arith: Arith, scalars, points, lens) -> np.ndarray:
     """`len(lens)` independent MulVecs in one launch."""
     sc = scalars_to_wire(scalars)

@@ -21,7 +21,11 @@ extern "C" int bpp_init(int curve_id, int device, bpp_ctx** out_ctx) {
     *out_ctx = new bpp_ctx{curve_id, device};
     return BPP_OK;
 }
-extern "C" void bpp_destroy(bpp_ctx* ctx) { delete ctx; }
+extern "C" void bpp_destroy(bpp_ctx* ctx) {
+    if (!ctx) return;
+    for (hipEvent_t e : ctx->msm_events) (void)hipEventDestroy(e);
+    delete ctx;
+}
 
 extern "C" int bpp_point_words(int curve_id) {
     switch (curve_id) {
@@ -75,8 +79,40 @@ extern "C" int bpp_msm_device(bpp_ctx* ctx, const uint64_t* d_scalars, const uin
         return MsmImpl<decltype(cv)>::msm_device(reinterpret_cast<const uint32_t*>(d_scalars),
                                                  reinterpret_cast<const uint32_t*>(d_points), n, window_bits,
                                                  reinterpret_cast<uint32_t*>(d_out), d_status, d_workspace, workspace_bytes,
-                                                 static_cast<hipStream_t>(stream));
+                                                 static_cast<hipStream_t>(stream), ctx);
     });
+}
+
+extern "C" int bpp_msm_set_profiling(bpp_ctx* ctx, int on) {
+    if (!ctx) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (on && ctx->msm_events.empty()) {
+        ctx->msm_events.resize(BPP_MSM_SLOTS * (PIP_STAGES + 1));
+        for (hipEvent_t& e : ctx->msm_events) HIPCHK(hipEventCreate(&e));
+    }
+    ctx->msm_profiling = on != 0;
+    ctx->msm_passes = 0;
+    return BPP_OK;
+}
+
+extern "C" int bpp_msm_profile(bpp_ctx* ctx, float* out_stage_ms, size_t* out_passes, uint32_t* out_shape) {
+    if (!ctx || !out_stage_ms) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t np = std::min<size_t>(ctx->msm_passes, BPP_MSM_SLOTS);
+    for (int t = 0; t < PIP_STAGES; t++) out_stage_ms[t] = 0.f;
+    for (size_t p = 0; p < np; p++) {
+        hipEvent_t* ev = ctx->msm_events.data() + p * (PIP_STAGES + 1);
+        for (int t = 0; t < PIP_STAGES; t++) {
+            HIPCHK(hipEventSynchronize(ev[t + 1]));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[t], ev[t + 1]));
+            out_stage_ms[t] += ms;
+        }
+    }
+    for (int t = 0; t < PIP_STAGES; t++) out_stage_ms[t] = np ? out_stage_ms[t] / (float)np : 0.f;
+    if (out_passes) *out_passes = np;
+    if (out_shape) std::memcpy(out_shape, ctx->msm_shape, sizeof ctx->msm_shape);
+    return BPP_OK;
 }
 
 extern "C" int bpp_scalar_mul_batch(bpp_ctx* ctx, const uint64_t* scalars, const uint64_t* points, size_t n,

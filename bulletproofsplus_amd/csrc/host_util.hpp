@@ -16,7 +16,13 @@
 struct bpp_ctx {
     int curve;
     int device;
-};
+    // per-stage timing of bpp_msm_device (bpp_msm_set_profiling): MSM_SLOTS passes x (stages + 1) events
+    bool msm_profiling = false;
+    size_t msm_passes = 0;
+    std::vector<hipEvent_t> msm_events;
+    uint32_t msm_shape[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // of the last bpp_msm_device call: n, items, W, q, nwide, nbuckets, L, c
+};   // (the events are destroyed by bpp_destroy: verifiers keep a COPY of their context)
+constexpr size_t BPP_MSM_SLOTS = 16;
 
 // Entry points of the per-curve implementation structs (impl_*.hpp, codec.hpp).  They are defined in class, hence
 // implicitly inline, and `extern template` does not stop the compiler from instantiating an inline function in order

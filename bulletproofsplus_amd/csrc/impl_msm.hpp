@@ -80,7 +80,8 @@ struct MsmImpl {
     static constexpr size_t PIPPENGER_MIN_N = 4096;
     static size_t msm_workspace_bytes(size_t n, int window_bits);
     static int msm_device(const uint32_t* d_scalars, const uint32_t* d_wire_points, size_t n, int window_bits,
-                          uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st);
+                          uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st,
+                          bpp_ctx* ctx = nullptr);
 
     // the same from host pointers (uploads, runs, downloads); explicit window width (tests sweep it)
     static int msm_pippenger(const uint64_t* scalars, const uint64_t* points, size_t n, int window_bits, uint64_t* out);
@@ -149,7 +150,8 @@ size_t MsmImpl<C>::msm_workspace_bytes(size_t n, int window_bits) {
 
 template <class C>
 int MsmImpl<C>::msm_device(const uint32_t* d_scalars, const uint32_t* d_wire_points, size_t n, int window_bits,
-                           uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st) {
+                           uint32_t* d_out_wire, uint32_t* d_status, void* d_ws, size_t ws_bytes, hipStream_t st,
+                           bpp_ctx* ctx) {
     if (n >= ((size_t)1 << 28)) return fail(BPP_E_ARG, "n too large");
     if (n == 0) {   // Point::zero()
         if (d_status) HIPCHK(zero_words_async(d_status, 4, st));
@@ -161,7 +163,13 @@ int MsmImpl<C>::msm_device(const uint32_t* d_scalars, const uint32_t* d_wire_poi
     int rc = pip_shape_for<C>(n, window_bits ? window_bits : pip_pick_c<C>(n), ps);
     if (rc) return rc;
     if (ws_bytes < pip_workspace<C>(ps).total) return fail(BPP_E_ARG, "workspace too small (bpp_msm_workspace_bytes)");
-    HIPCHK(pip_launch<C>(ps, d_scalars, d_wire_points, static_cast<uint8_t*>(d_ws), d_out_wire, d_status, st));
+    hipEvent_t* ev = nullptr;
+    if (ctx) {
+        const uint32_t sh[8] = {ps.n, ps.items, ps.W, ps.q, ps.nwide, ps.nbuckets, ps.L, ps.c};
+        std::memcpy(ctx->msm_shape, sh, sizeof sh);
+        if (ctx->msm_profiling) ev = ctx->msm_events.data() + (ctx->msm_passes++ % BPP_MSM_SLOTS) * (PIP_STAGES + 1);
+    }
+    HIPCHK(pip_launch<C>(ps, d_scalars, d_wire_points, static_cast<uint8_t*>(d_ws), d_out_wire, d_status, st, ev));
     return BPP_OK;
 }
 

@@ -89,6 +89,15 @@ size_t bpp_msm_workspace_bytes(bpp_ctx *ctx, size_t n, int window_bits);
 int bpp_msm_device(bpp_ctx *ctx, const uint64_t *d_scalars, const uint64_t *d_points, size_t n, int window_bits,
                    uint64_t *d_out, uint32_t *d_status, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Per-stage timing of bpp_msm_device with HIP events recorded on the caller's stream (stages: 0 sort = points from
+ * wire, digits + histogram, scans, scatter; 1 bucket sums, chunk by chunk [dominant: k_pip_chunks]; 2 fold of the
+ * segments into buckets; 3 bucket reduction per tile and per window; 4 doublings + final sum + affine point).
+ * bpp_msm_profile averages over the calls recorded since profiling was switched on (at most 16): out_stage_ms[5];
+ * out_shape (may be NULL) receives the geometry of the last call: n, items, windows, narrow window bits, wide
+ * windows, buckets, entries per chunk, requested window bits. */
+int bpp_msm_set_profiling(bpp_ctx *ctx, int on);
+int bpp_msm_profile(bpp_ctx *ctx, float *out_stage_ms, size_t *out_passes, uint32_t *out_shape);
+
 /* `count` independent MulVecs in one launch: MulVec c has lens[c] terms starting at offset
  * sum(lens[0..c)).  out: count points.  (The fold of src/weighted_inner_product_proof.rs:151-163 is
  * 2 n' MulVecs of length 2.)  Host pointers. */
