@@ -57,6 +57,45 @@ MSM_ORDER = {"bls12_381": 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFF
              "ed25519": (1 << 252) + 27742317777372353535851937790883648493}
 
 
+FR_BITS = {"bls12_381": 255, "secp256k1": 256, "ed25519": 253}
+
+
+def loop_peaks(curve):
+    """(G mixed additions/s of the register-resident loop, T v_mad_u64_u32 lane-ops/s, source file) recorded by
+    tools/ubench.hip on this GPU model under profiles/ -- not measured in this run"""
+    for cand in ("ubench_r02.json", "ubench_r01_final.json"):
+        try:
+            uj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}.get(curve)
+            if key is None:
+                return None, uj["v_mad_u64_u32"]["Gops"] / 1e3, "profiles/" + cand
+            if key not in uj:
+                key = key.replace("_lazy", "")
+            return uj[key]["Gops"], uj["v_mad_u64_u32"]["Gops"] / 1e3, "profiles/" + cand
+        except Exception:
+            continue
+    return None, None, None
+
+
+def verify_roofline(curve, n, m, batch, window_bits, kernel_ms, fp_bytes, kernel="k_fixed_msm", launches=None):
+    """The roofline block of a verification leg, with the accounting of the headline: algorithmic bytes of one launch of
+    the dominant kernel = batch x (2mn + 2) fixed terms x (affine point + scalar), against its mean duration
+    (HIP events on the launch stream); `alu`: its table additions per second against the register-resident loop."""
+    NF = 2 * n * m + 2
+    term = 2 * fp_bytes + 32
+    alg = batch * NF * term
+    windows = (FR_BITS[curve] - 1) // window_bits + 1
+    adds = batch * NF * windows
+    ach = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    rate = adds / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    add_peak, _, src = loop_peaks(curve)
+    return {"bound": "hbm", "limiter": "alu", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": kernel_ms,
+            "launches_timed": launches,
+            "alu": {"unit": "G mixed additions/s", "achieved": rate, "peak": add_peak,
+                    "frac": (rate / add_peak) if add_peak else None, "additions_per_launch": adds, "peak_source": src}}
+
+
 def synth_values(seed, m):
     """v_j = (0x9E3779B97F4A7C15 * (j+1+seed)) mod 2^31 (< 2^31 because of prover.rs:37), gamma_j = j+3+seed"""
     vals = [((0x9E3779B97F4A7C15 * (j + 1 + seed)) & 0xFFFFFFFFFFFFFFFF) % (1 << 31) for j in range(m)]
@@ -263,6 +302,12 @@ def main():
     ap.add_argument("--prove-steps", type=int, default=2, help="steps of the device-resident batched prover leg; 0 = skip")
     ap.add_argument("--serialized-steps", type=int, default=3,
                     help="steps of the serialized-input leg (containers + compressed commitments resident in HBM); 0 = skip")
+    ap.add_argument("--sustained-steps", type=int, default=0,
+                    help="extra back-to-back steps of the headline pass after the timed region (a 200-step run is kept in profiles/)")
+    ap.add_argument("--production-steps", type=int, default=3,
+                    help="steps of the production-path leg (hashed generators + transcript + serialized input); 0 = skip")
+    ap.add_argument("--single-call-reps", type=int, default=5,
+                    help="calls per point of the single_call leg (bpp_range_prove / bpp_range_verify, host pointers); 0 = skip")
     ap.add_argument("--msm-steps", type=int, default=5,
                     help="steps per point of the `msm` leg (device-resident general MulVec, N = 2^16 .. 2^22 on the three curves); 0 = skip")
     ap.add_argument("--msm-log2n", type=int, nargs="+", default=[16, 18, 20, 22])
@@ -369,20 +414,34 @@ def main():
     d_fail = torch.zeros(1, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    comm_ev = []   # (before, after) events around the exchange step of every timed step (world > 1)
+
     def step(_i=0):
         bv.run_device(d_pts.data_ptr(), d_sc.data_ptr(), Bsz, d_ok.data_ptr(), d_ws.data_ptr(), wsb, stream)
         if dist is not None:
             # the one exchange step of the path: batch verdict = sum of per-proof failures over all ranks
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             torch.sum(d_ok, dim=0, keepdim=True, out=d_fail)
             allreduce_sum_i32(d_fail)
+            e1.record()
+            comm_ev.append((e0, e1))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     bv.set_profiling(True)
+    comm_ev.clear()
     dt = timed(step, args.steps, torch, dist, coll_dev)
     stage_ms, passes, bpp_ = bv.profile()
     bv.set_profiling(False)
+    comm_ms = (sum(e0.elapsed_time(e1) for e0, e1 in comm_ev) / len(comm_ev)) if comm_ev else None
+    # sustained: the same step many times back to back (clock drift / thermal check of the short timed region)
+    sustained = None
+    if args.sustained_steps > 0:
+        sdt_ = timed(step, args.sustained_steps, torch, dist, coll_dev)
+        sustained = {"steps": args.sustained_steps, "seconds": sdt_, "value": world * Bsz * args.sustained_steps / sdt_,
+                     "ms_per_step": sdt_ / args.sustained_steps * 1e3}
     ok = d_ok.cpu().numpy()
     assert int(ok.sum()) == 0, "a valid proof failed to verify"
     if dist is not None:
@@ -474,15 +533,45 @@ def main():
 
         pstep_fs(0)
         pdt_fs = timed(pstep_fs, args.prove_steps, torch, dist, coll_dev)
+        # untimed: the transcript-mode proofs the timed prover just wrote verify under the transcript, and a tampered
+        # subset is rejected exactly
+        recs_fs = torch.cat([d_po, d_pV], dim=1).contiguous()
+        d_chf = torch.zeros((Pn, 3 + kk, 4), dtype=torch.int64, device=dev)
+        bv.derive_challenges_device(recs_fs.data_ptr(), Pn, d_chf.data_ptr())
+        sc_fs = d_ps.cpu().numpy().view(np.uint64).copy()
+        Kp = min(32, Pn)
+        which_p = np.sort(np.random.RandomState(31 + rank).choice(Pn, size=Kp, replace=False))
+        for j, i in enumerate(which_p):
+            sc_fs[i, j % 3, 0] ^= np.uint64(1 << (j % 50))
+        d_scf = torch.from_numpy(sc_fs.view(np.int64)).to(dev)
+        d_okp = torch.full((Pn,), 7, dtype=torch.int32, device=dev)
+        wsp = bv.workspace_bytes(Pn)
+        bv.run_device(recs_fs.data_ptr(), d_scf.data_ptr(), Pn, d_okp.data_ptr(), d_ws.data_ptr(), wsp, stream,
+                      d_challenges=d_chf.data_ptr())
+        torch.cuda.synchronize()
+        want_p = np.zeros(Pn, dtype=np.int32)
+        want_p[which_p] = 1
+        assert np.array_equal(d_okp.cpu().numpy(), want_p), "prove leg: transcript-mode proofs / tampered subset: wrong verdicts"
+        # MulVec terms of one RangeProof::prove: A-hat (mn + m + 3), L_t and R_t (2 n' + 2 each), wip.A (4),
+        # wip.B (2), and 2 per commitment; the prover's launches run them over the fixed generators' tables
+        mn_ = n * m
+        prove_terms = (mn_ + m + 3) + 4 * (mn_ - 1) + 4 * kk + 6 + 2 * m
+        palg = Pn * prove_terms * (2 * ((a.PW - 1) // 2 * 8) + 32)
         prove = {"value": world * Pn * args.prove_steps / pdt, "unit": "proofs/s", "batch": Pn, "steps": args.prove_steps,
                  "ms_per_step": pdt / args.prove_steps * 1e3,
+                 "verified": {"transcript_proofs": int(Pn), "tampered": int(Kp), "verdicts_exact": True},
+                 "roofline": {"bound": "hbm", "limiter": "alu", "kernel": "k_fixed_msm<..., 2> (+ k_pb_*): the whole step",
+                              "algorithmic_bytes_per_launch": palg, "mulvec_terms_per_proof": prove_terms,
+                              "kernel_ms": pdt / args.prove_steps * 1e3,
+                              "achieved": palg / (pdt / args.prove_steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": palg / (pdt / args.prove_steps) / 1e9 / HBM_PEAK_GBS, "traffic": None},
                  "transcript_mode": {"value": world * Pn * args.prove_steps / pdt_fs, "unit": "proofs/s",
                                      "ms_per_step": pdt_fs / args.prove_steps * 1e3,
                                      "note": "challenges from the SHA-256 transcript on the device, round by round "
                                              "(engine mode; the reference hard-codes its challenges)"},
                  "note": "RangeProof::prove + the m commitments per proof, inputs and outputs resident in HBM; "
                          "bit-identical to the single-proof path (tests/test_gpu_protocol.py)"}
-        del d_pws, d_po, d_ps, d_pV
+        del d_pws, d_po, d_ps, d_pV, recs_fs, d_chf, d_scf, d_okp
 
     # ---- secondary, separately timed: the same batch arriving SERIALIZED (the proof container + compressed
     # commitments, resident in HBM): header / encoding / subgroup / canonicity checks and decompression on the device,
@@ -505,8 +594,67 @@ def main():
                                         stream)
 
         sstep(0)
+        bv.set_profiling(True)
         sdt = timed(sstep, args.serialized_steps, torch, dist, coll_dev)
+        sst, _, _ = bv.profile()
+        bv.set_profiling(False)
         assert int(d_sok.cpu().numpy().sum()) == 0, "a valid serialized proof failed to verify"
+        # untimed: a batch with bad containers must give EXACTLY the expected status vector: 1 for a tampered r' / s' /
+        # delta', 2 (FormatError) for a bad header byte, a non-canonical scalar, a malformed point encoding and -- on
+        # BLS12-381 -- a curve point outside G1
+        cbytes = comm.shape[2]
+        hdr, pt0 = 12, 12
+        sc0 = hdr + npp * cbytes
+        bl_bad = np.ascontiguousarray(blobs).copy()
+        Ks = min(60, Bsz)
+        rs_s = np.random.RandomState(999 + rank)
+        which_s = np.sort(rs_s.choice(Bsz, size=Ks, replace=False))
+        want_s = np.zeros(Bsz, dtype=np.int64)
+        order_s = MSM_ORDER[args.curve]
+        torsion = None
+        if args.curve == "bls12_381":
+            import ctypes as _ct
+            # (0, 2) has order 3 on y^2 = x^3 + 4: P + (0, 2) is on the curve and outside G1; its compressed form comes from
+            # the engine's own group law (bpp_debug_point_op, op 0 = add)
+            Tw = np.zeros(a.PW, dtype=np.uint64)
+            Tw[(a.PW - 1) // 2] = 2
+            mixed = np.zeros(a.PW, dtype=np.uint64)
+            from bulletproofsplus_amd import _lib as _L
+            assert _L.lib().bpp_debug_point_op(a.handle, 0, pts_[0, 1].ctypes.data_as(_ct.c_void_p), Tw.ctypes.data_as(_ct.c_void_p), 1,
+                                               mixed.ctypes.data_as(_ct.c_void_p)) == 0
+            torsion = B.compress_points(a, mixed[None])[0]
+        for j, i in enumerate(which_s):
+            kind = j % 5
+            if kind == 0:
+                bl_bad[i, sc0 + 32 * (j % 3)] ^= 1 << (j % 7)           # tampered scalar, still canonical with overwhelming probability
+                val = int.from_bytes(bytes(bl_bad[i, sc0 + 32 * (j % 3):sc0 + 32 * (j % 3) + 32]), "little")
+                want_s[i] = 1 if val < order_s else 2
+            elif kind == 1:
+                bl_bad[i, 4 + (j % 5)] ^= 0x40                            # version / curve / n / m / k byte of the header
+                want_s[i] = 2
+            elif kind == 2:
+                v0 = int.from_bytes(bytes(bl_bad[i, sc0:sc0 + 32]), "little") + order_s
+                if v0 < (1 << 256):
+                    bl_bad[i, sc0:sc0 + 32] = np.frombuffer(v0.to_bytes(32, "little"), dtype=np.uint8)   # r' + r: non-canonical
+                    want_s[i] = 2
+            elif kind == 3:
+                bl_bad[i, pt0 + cbytes * 3] ^= (0x80 if args.curve == "bls12_381" else 0x05)   # L_0: compression flag / prefix byte
+                want_s[i] = 2
+            else:
+                bl_bad[i, sc0 + 64 + 1] ^= 2                              # delta'
+                val = int.from_bytes(bytes(bl_bad[i, sc0 + 64:sc0 + 96]), "little")
+                want_s[i] = 1 if val < order_s else 2
+        if torsion is not None:       # proof 0's wip.A replaced by wip.A + T (T of order 3)
+            bl_bad[0, pt0 + cbytes:pt0 + 2 * cbytes] = torsion
+            want_s[0] = 2
+        d_bl_bad = torch.from_numpy(bl_bad).to(dev)
+        d_sok.fill_(7)
+        bv.verify_serialized_device(d_bl_bad.data_ptr(), d_cm.data_ptr(), Bsz, d_sok.data_ptr(), d_sws.data_ptr(), swsb, stream)
+        torch.cuda.synchronize()
+        got_s = d_sok.cpu().numpy().astype(np.int64)
+        assert np.array_equal(got_s, want_s), "serialized leg: status vector differs from the expected one at %s" % \
+            np.nonzero(got_s != want_s)[0][:8].tolist()
+        del d_bl_bad
         in_bytes = blobs.shape[1] + m * comm.shape[2]
         # PCIe-inclusive: the same call preceded by the host-to-device copy of the bytes (pinned host memory)
         h_bl, h_cm = torch.from_numpy(np.ascontiguousarray(blobs)).pin_memory(), torch.from_numpy(np.ascontiguousarray(comm)).pin_memory()
@@ -523,6 +671,12 @@ def main():
                       "points_decoded_per_proof": int(npp + m),
                       "from_pinned_host": {"value": world * Bsz * args.serialized_steps / sdt_h, "unit": "verifies/s",
                                            "ms_per_step": sdt_h / args.serialized_steps * 1e3},
+                      "stage_ms": {k: round(v, 4) for k, v in sst.items()},
+                      "decode_ms": sdt / args.serialized_steps * 1e3 - sum(sst.values()),
+                      "status_check": {"bad_containers": int((want_s != 0).sum()), "statuses_exact": True,
+                                       "kinds": "tampered scalars (1); header byte, non-canonical scalar, malformed point, point outside G1 (2)"},
+                      "roofline": verify_roofline(args.curve, n, m, Bsz, args.window, sst["fixed_msm"], (a.PW - 1) // 2 * 8,
+                                                  launches=args.serialized_steps),
                       "note": "input = the versioned proof container + compressed commitments (include/bpp_amd.h), already in "
                               "HBM; decode (square root, G1 subgroup check, canonicity) + verification; `from_pinned_host` "
                               "adds the PCIe copy of those bytes.  Engine data format: the reference never serializes"}
@@ -673,17 +827,33 @@ def main():
         odt = timed(ostep, steps, torch, dist, coll_dev)
         ost, _, obpp = bv_o.profile()
         bv_o.set_profiling(False)
-        # and one tampered proof in the middle of the batch must be the only one rejected
+        # untimed: the same geometry with a tampered subset must give EXACTLY the expected verdict vector (r', s', delta'
+        # bit flips and, among distinct proofs, the A of another proof)
+        Kt = min(64, batch)
+        rs_t = np.random.RandomState(4242 + rank)
+        which = np.sort(rs_t.choice(batch, size=Kt, replace=False))
         sc_bad = scs_o.copy()
-        sc_bad[batch // 2, 1, 0] ^= np.uint64(4)
-        d_sc_b = torch.from_numpy(sc_bad.view(np.int64)).to(dev)
-        bv_o.run_device(d_pts_o.data_ptr(), d_sc_b.data_ptr(), batch, d_ok_o.data_ptr(), d_ws_o.data_ptr(), wsb_o, stream)
+        rec_bad = recs_o.copy()
+        for j, i in enumerate(which):
+            if j % 4 < 3 or Do < 2 or np.array_equal(recs_o[(i + 1) % batch, 0], recs_o[i, 0]):
+                sc_bad[i, j % 3, 0] ^= np.uint64(1 << (j % 60))
+            else:
+                rec_bad[i, 0] = recs_o[(i + 1) % batch, 0]
+        d_sc_b = torch.from_numpy(np.ascontiguousarray(sc_bad).view(np.int64)).to(dev)
+        d_pts_b = torch.from_numpy(np.ascontiguousarray(rec_bad).view(np.int64)).to(dev)
+        d_ok_o.fill_(7)
+        bv_o.run_device(d_pts_b.data_ptr(), d_sc_b.data_ptr(), batch, d_ok_o.data_ptr(), d_ws_o.data_ptr(), wsb_o, stream)
         torch.cuda.synchronize()
         got = d_ok_o.cpu().numpy()
-        assert got[batch // 2] == 1 and int(got.sum()) == 1, "%s (%d,%d): tampered proof not singled out" % (curve, n_, m_)
+        want = np.zeros(batch, dtype=got.dtype)
+        want[which] = 1
+        assert np.array_equal(got, want), "%s (%d,%d): tampered batch: verdict vector differs from the expected one" % (curve, n_, m_)
+        del d_pts_b
         res = {"value": world * batch * steps / odt, "unit": "verifies/s", "steps": steps, "ms_per_step": odt / steps * 1e3,
                "batch": batch, "window_bits": window_bits, "table_bytes": bv_o.table_bytes, "msm_terms_per_verify": bv_o.msm_len,
-               "stage_ms": {k: round(v, 4) for k, v in ost.items()}, "blocks_per_proof": obpp}
+               "stage_ms": {k: round(v, 4) for k, v in ost.items()}, "blocks_per_proof": obpp,
+               "tamper_check": {"tampered": int(Kt), "verdicts_exact": True},
+               "roofline": verify_roofline(curve, n_, m_, batch, window_bits, ost["fixed_msm"], (a_o.PW - 1) // 2 * 8, launches=steps)}
         bv_o.close()
         del d_ws_o, d_pts_o, d_sc_o, d_sc_b
         torch.cuda.empty_cache()
@@ -709,6 +879,153 @@ def main():
             others[oc] = side_leg(oc, n, m, Bsz, 17 if oc == "ed25519" else 16, args.other_curves_steps)
             others[oc]["parity"] = ("unpinned: not a reference backend; the prime-order subgroup of the curve under Ristretto255"
                                     if oc == "ed25519" else "the reference's second in-tree backend (not wired to its range proof)")
+
+    # ---- secondary, separately timed: the PRODUCTION path -- what a maintainer adopting the README's API
+    # (README.md:24-57: a transcript threaded through prove and verify) would run: generators hashed from a label
+    # (bpp_pk_hashed; no known discrete logs), proofs made under the Fiat-Shamir transcript with blinding from a fresh
+    # key, serialized, and then -- timed -- bytes in HBM -> decode -> derive challenges -> verify -> statuses.
+    production = None
+    if args.production_steps > 0 and args.curve == "bls12_381" and args.config == "c2":
+        release_main()
+        production = {}
+        for (pn, pm, pbatch, pwin) in ((n, m, Bsz, args.window), (64, 1, 4096, 16)):
+            a_p = B.Arith.init("bls12_381", local_rank)
+            pk_p = B.PublicKey.hashed(a_p, pn * pm, b"bench production leg")
+            bv_p = None
+            while bv_p is None:
+                try:
+                    bv_p = B.BatchVerifier(pk_p, pn, pm, window_bits=pwin)
+                except B.BppError as e:
+                    if e.code != -5 or pwin <= 10:
+                        raise
+                    pwin -= 1
+            kp = (pn * pm).bit_length() - 1
+            Dp = min(pbatch, 2048)
+            pv = np.array([synth_values(rank * 1000003 + d * 17, pm)[0] for d in range(Dp)], dtype=np.uint64)
+            pg = np.zeros((Dp, pm, 4), dtype=np.uint64)
+            for d in range(Dp):
+                pg[d, :, 0] = np.array(synth_values(rank * 1000003 + d * 17, pm)[1], dtype=np.uint64)
+            pts_p, scs_p, V_p = bv_p.prove_batch(pv, pg, transcript=True, blind_key=os.urandom(32), index_base=rank * pbatch)
+            blobs_p = B.encode_proofs(a_p, pn, pm, pts_p, scs_p)
+            comm_p = B.compress_points(a_p, V_p.reshape(-1, a_p.PW)).reshape(Dp, pm, -1)
+            ix = np.arange(pbatch) % Dp
+            blobs_p, comm_p = np.ascontiguousarray(blobs_p[ix]), np.ascontiguousarray(comm_p[ix])
+            d_bl_p = torch.from_numpy(blobs_p).to(dev)
+            d_cm_p = torch.from_numpy(comm_p).to(dev)
+            swsb_p = bv_p.serialized_workspace_bytes(pbatch)
+            d_sws_p = torch.empty(swsb_p, dtype=torch.uint8, device=dev)
+            d_ok_p = torch.full((pbatch,), 7, dtype=torch.int32, device=dev)
+
+            def prstep(_i):
+                bv_p.verify_serialized_device(d_bl_p.data_ptr(), d_cm_p.data_ptr(), pbatch, d_ok_p.data_ptr(), d_sws_p.data_ptr(),
+                                              swsb_p, stream, transcript=True)
+            prstep(0)
+            torch.cuda.synchronize()
+            assert int(d_ok_p.cpu().numpy().sum()) == 0, "production leg: a valid proof failed to verify"
+            bv_p.set_profiling(True)
+            prdt = timed(prstep, args.production_steps, torch, dist, coll_dev)
+            prst, _, _ = bv_p.profile()
+            bv_p.set_profiling(False)
+            # the derive step alone (SHA-256 transcript over the decoded records), on the records of the last pass
+            recs_p = np.ascontiguousarray(np.concatenate([pts_p, V_p], axis=1)[ix])
+            d_rec_p = torch.from_numpy(recs_p.view(np.int64)).to(dev)
+            d_ch_p = torch.zeros((pbatch, 3 + kp, 4), dtype=torch.int64, device=dev)
+            ddt = timed(lambda i: bv_p.derive_challenges_device(d_rec_p.data_ptr(), pbatch, d_ch_p.data_ptr()),
+                        args.production_steps, torch, None, dev)
+            # untimed: tampered subset -> exact statuses (1 for a flipped scalar bit; every proof point is bound by the transcript)
+            Kq = min(48, pbatch)
+            which_q = np.sort(np.random.RandomState(55 + rank).choice(pbatch, size=Kq, replace=False))
+            bl_q = blobs_p.copy()
+            cbp = comm_p.shape[2]
+            sc0p = 12 + (3 + 2 * kp) * cbp
+            want_q = np.zeros(pbatch, dtype=np.int64)
+            for j, i in enumerate(which_q):
+                if j % 2 == 0:
+                    bl_q[i, sc0p + 32 * (j % 3) + 2] ^= 1 << (j % 8)
+                    val = int.from_bytes(bytes(bl_q[i, sc0p + 32 * (j % 3):sc0p + 32 * (j % 3) + 32]), "little")
+                    want_q[i] = 1 if val < MSM_ORDER["bls12_381"] else 2
+                else:
+                    bl_q[i, 5] ^= 1                                       # curve byte of the header
+                    want_q[i] = 2
+            d_bl_q = torch.from_numpy(bl_q).to(dev)
+            d_ok_p.fill_(7)
+            bv_p.verify_serialized_device(d_bl_q.data_ptr(), d_cm_p.data_ptr(), pbatch, d_ok_p.data_ptr(), d_sws_p.data_ptr(), swsb_p,
+                                          stream, transcript=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_ok_p.cpu().numpy().astype(np.int64), want_q), "production leg: status vector differs from the expected one"
+            ms_p = prdt / args.production_steps * 1e3
+            derive_ms = ddt / args.production_steps * 1e3
+            production["n=%d,m=%d" % (pn, pm)] = {
+                "value": world * pbatch * args.production_steps / prdt, "unit": "verifies/s", "batch": pbatch, "steps": args.production_steps,
+                "ms_per_step": ms_p, "window_bits": pwin, "table_bytes": bv_p.table_bytes,
+                "bytes_per_proof": int(blobs_p.shape[1] + pm * cbp),
+                "stage_ms": {"decode": round(ms_p - sum(prst.values()) - derive_ms, 4), "derive_challenges": round(derive_ms, 4),
+                             **{k: round(v, 4) for k, v in prst.items()}},
+                "status_check": {"tampered": int(Kq), "statuses_exact": True},
+                "roofline": verify_roofline("bls12_381", pn, pm, pbatch, pwin, prst["fixed_msm"], (a_p.PW - 1) // 2 * 8,
+                                            launches=args.production_steps),
+                "note": "generators hashed from a label (bpp_pk_hashed), proofs made under the SHA-256 transcript with blinding from a "
+                        "fresh key, serialized containers + compressed commitments resident in HBM; timed: decode (square root, G1 "
+                        "subgroup check) + challenge derivation + verification + status words; parity unpinned by the reference "
+                        "(it has neither transcript nor serialization nor hashed generators)"}
+            bv_p.close()
+            del d_sws_p, d_bl_p, d_cm_p, d_rec_p, d_ch_p, d_bl_q
+            torch.cuda.empty_cache()
+
+    # ---- secondary: the LITERAL single-call API (src/range/mod.rs:31-78, src/main.rs:10-56): RangeProof::prove and
+    # RangeProof::verify with host pointers and no verifier object, one proof per call.  ms per call, synchronous,
+    # PCIe and allocations included.  verify: first call with a key = naive MulVec; second = builds that key's small
+    # window tables; later calls = cached tables (include/bpp_amd.h, bpp_range_verify).
+    single = None
+    if args.single_call_reps > 0 and world == 1 and args.curve == "bls12_381":
+        release_main()
+        single = {}
+        for (sn, sm) in ((32, 1), (64, 2), (64, 16)):
+            a_s = B.Arith("bls12_381", local_rank)       # a context of its own: a clean verifier cache
+            pk_s = B.PublicKey.new(a_s, sn * sm)
+            pr_s = B.RangeProver.new()
+            sv, sg = synth_values(5, sm)
+            if (sn, sm) == (64, 2):
+                sv, sg = [2, 5], [3, 7]                   # src/main.rs:20-27
+            if sn < 64:
+                sv = [v_ % (1 << sn) for v_ in sv]
+            for v_, g_ in zip(sv, sg):
+                pr_s.commit(pk_s, v_, g_)
+            t0 = time.perf_counter()
+            proof_s = B.RangeProof.prove(pk_s, sn, pr_s)
+            t_first_prove = time.perf_counter() - t0
+            tp = []
+            for _ in range(args.single_call_reps):
+                t0 = time.perf_counter()
+                proof_s = B.RangeProof.prove(pk_s, sn, pr_s)
+                tp.append(time.perf_counter() - t0)
+            tv = []
+            for _ in range(2 + args.single_call_reps):
+                t0 = time.perf_counter()
+                proof_s.verify(pk_s, sn, pr_s.commitment_vec)     # raises on a wrong verdict
+                tv.append(time.perf_counter() - t0)
+            bad_s = B.RangeProof.from_wire(proof_s.points_wire(), proof_s.scalars_wire())
+            bad_s.proof.r_prime = bad_s.proof.r_prime.copy()
+            bad_s.proof.r_prime[0] ^= np.uint64(1)
+            rejected = False
+            try:
+                bad_s.verify(pk_s, sn, pr_s.commitment_vec)
+            except B.VerificationError:
+                rejected = True
+            assert rejected, "single_call: a tampered proof verified"
+            a_s.set_verify_cache(False)
+            tn = []
+            for _ in range(args.single_call_reps):
+                t0 = time.perf_counter()
+                proof_s.verify(pk_s, sn, pr_s.commitment_vec)
+                tn.append(time.perf_counter() - t0)
+            single["n=%d,m=%d" % (sn, sm)] = {
+                "prove_ms": min(tp) * 1e3, "prove_first_call_ms": t_first_prove * 1e3,
+                "verify_first_call_ms": tv[0] * 1e3, "verify_second_call_builds_tables_ms": tv[1] * 1e3,
+                "verify_cached_ms": min(tv[2:]) * 1e3, "verify_uncached_ms": min(tn) * 1e3,
+                "msm_terms_per_verify": 2 * sn * sm + 2 * ((sn * sm).bit_length() - 1) + sm + 5}
+        single["note"] = ("RangeProof::prove / RangeProof::verify through bpp_range_prove / bpp_range_verify: host pointers, one proof, "
+                          "synchronous, wall clock of the call (best of %d); the tampered proof of each shape is rejected" % args.single_call_reps)
 
     # ---- secondary, separately timed: MulVec::calculate as a seam of its own at large N (bpp_msm_device) ---------
     # scalars and points resident in HBM, full-width scalars, distinct points k_i g (made on the GPU); every size is
@@ -841,7 +1158,9 @@ def main():
             "data": "synthetic: %d distinct GPU-proved proofs per GPU in a batch of %d; reference constants as transcript" % (D, Bsz),
             "config": {"workload": "%s: n=%d m=%d range-proof verify, %s, batch %d per GPU, per-proof verdicts" % (args.config, n, m, args.curve, Bsz),
                        "curve": args.curve, "msm_terms_per_verify": N_msm, "window_bits": args.window,
-                       "table_bytes": table_bytes_main, "parallelism": "proof-sharded x%d" % world,
+                       "table_bytes": table_bytes_main,
+                       "table_frac_of_hbm": table_bytes_main / float(torch.cuda.get_device_properties(dev).total_memory),
+                       "parallelism": "proof-sharded x%d" % world,
                        "launcher": "bench.py spawned the ranks" if os.environ.get("BPP_BENCH_LAUNCHED") else
                                    ("external launcher" if world > 1 else "single process"),
                        "backend": backend if dist is not None else None},
@@ -871,6 +1190,10 @@ def main():
             "hard_distribution": hard,
             "other_curves": others,
             "msm": msm,
+            "production": production,
+            "single_call": single,
+            "sustained": sustained,
+            "comm_ms": comm_ms,
             "setup_s": {"prove_batch_%d" % D: t_prove, "tables": t_tables},
         }
         if args.cpu_seconds > 0 and world == 1 and args.curve != "ed25519":   # the C oracle has no Edwards backend

@@ -28,11 +28,11 @@ FORMAT_ERROR = 2   # ProofError::FormatError (reference src/errors.rs:20)
 EXPORTS = [
     "bpp_init", "bpp_destroy", "bpp_last_error", "bpp_point_words", "bpp_msm", "bpp_msm_batch", "bpp_msm_pippenger",
     "bpp_msm_workspace_bytes", "bpp_msm_device", "bpp_msm_set_profiling", "bpp_msm_profile",
-    "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_pk_hashed", "bpp_commit", "bpp_range_prove", "bpp_range_prove_batch", "bpp_range_verify", "bpp_wip_fold_round",
+    "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_pk_hashed", "bpp_commit", "bpp_range_prove", "bpp_range_prove_batch", "bpp_range_verify", "bpp_set_verify_cache", "bpp_wip_fold_round",
     "bpp_prover_workspace_bytes", "bpp_range_prove_batch_device",
     "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
     "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
-    "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_partial_bytes",
+    "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_set_subgroup_check", "bpp_verifier_partial_bytes",
     "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
     "bpp_verifier_derive_challenges", "bpp_range_prove_batch_fs", "bpp_range_prove_batch_fs_device",
     "bpp_point_compressed_bytes", "bpp_points_compress", "bpp_points_decompress", "bpp_points_decompress_device",
@@ -81,6 +81,7 @@ def lib():
         L.bpp_commit.argtypes = [vp, vp, u64, vp, vp]
         L.bpp_range_prove.argtypes = [vp, vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
         L.bpp_wip_fold_round.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
+        L.bpp_set_verify_cache.argtypes = [vp, i32]
         L.bpp_range_verify.argtypes = [vp, vp, vp, vp, sz, sz, vp, sz, vp, vp]
         L.bpp_range_prove_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
         L.bpp_prover_workspace_bytes.argtypes = [vp, sz]
@@ -99,6 +100,7 @@ def lib():
         L.bpp_range_verify_batch.argtypes = [vp, vp, vp, sz, vp]
         L.bpp_verifier_dominant_kernel.restype = ctypes.c_char_p
         L.bpp_verifier_set_profiling.argtypes = [vp, i32]
+        L.bpp_verifier_set_subgroup_check.argtypes = [vp, i32]
         L.bpp_verifier_profile.argtypes = [vp, vp, vp, vp]
         L.bpp_verifier_partial_bytes.argtypes = [vp]
         L.bpp_verifier_partial_bytes.restype = sz
@@ -106,14 +108,14 @@ def lib():
         L.bpp_verifier_combined_workspace_bytes.restype = sz
         L.bpp_verifier_run_combined.argtypes = [vp, vp, vp, sz, vp, ctypes.c_char_p, u64, vp, vp, vp, vp, sz, vp]
         L.bpp_verifier_derive_challenges.argtypes = [vp, vp, sz, vp, vp]
-        L.bpp_range_prove_batch_fs.argtypes = [vp, vp, vp, sz, vp, vp, vp]
-        L.bpp_range_prove_batch_fs_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp, sz, vp]
+        L.bpp_range_prove_batch_fs.argtypes = [vp, vp, vp, sz, ctypes.c_char_p, u64, vp, vp, vp]
+        L.bpp_range_prove_batch_fs_device.argtypes = [vp, vp, vp, sz, ctypes.c_char_p, u64, vp, vp, vp, vp, vp, vp, sz, vp]
         L.bpp_verifier_sum_partials.argtypes = [vp, vp, sz, vp, vp]
         L.bpp_point_compressed_bytes.argtypes = [i32]
         L.bpp_point_compressed_bytes.restype = sz
         L.bpp_points_compress.argtypes = [vp, vp, sz, vp]
         L.bpp_points_decompress.argtypes = [vp, vp, sz, vp, vp]
-        L.bpp_points_decompress_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.bpp_points_decompress_device.argtypes = [vp, vp, sz, vp, vp, i32, vp]
         L.bpp_range_verify_batch_compressed.argtypes = [vp, vp, vp, sz, vp]
         L.bpp_proof_bytes.argtypes = [i32, sz, sz]
         L.bpp_proof_bytes.restype = sz

@@ -87,6 +87,10 @@ class Arith:
             cls._ctxs[key] = cls(curve, device)
         return cls._ctxs[key]
 
+    def set_verify_cache(self, on: bool):
+        """the per-key small-table verifiers behind RangeProof.verify (include/bpp_amd.h, bpp_range_verify); on by default"""
+        check(_lib.lib().bpp_set_verify_cache(self.handle, 1 if on else 0), "bpp_set_verify_cache")
+
     # Point::zero()
     def zero_point(self) -> np.ndarray:
         z = np.zeros(self.PW, dtype=np.uint64)
@@ -594,10 +598,11 @@ def _verifier_sum_partials_device(self, d_partials: int, n: int, d_ok: int, stre
           "bpp_verifier_sum_partials")
 
 
-def _engine_prove_batch(self, values, gammas, transcript: bool = False):
+def _engine_prove_batch(self, values, gammas, transcript: bool = False, blind_key: bytes = None, index_base: int = 0):
     """RangeProof::prove + RangeProver::commit for `count` provers sharing this engine's (pk, n, m).
     transcript=True: challenges from the Fiat-Shamir transcript (csrc/transcript.hpp) instead of the reference's
-    constants -- not a reference code path, parity unpinned.
+    constants -- not a reference code path, parity unpinned.  blind_key (32 secret bytes, transcript mode only): the
+    blinding values come from this key (include/bpp_amd.h "Blinding"); None = the reference's literals, which hide nothing.
     values: (count, m) ints < 2^64 ; gammas: (count, m) scalars (ints or (count, m, 4) uint64).
     Returns (points (count, 3+2k, PW), scalars (count, 3, 4), V (count, m, PW)) in wire format --
     bit-identical to RangeProof.prove / RangeProver.commit one by one."""
@@ -614,8 +619,14 @@ def _engine_prove_batch(self, values, gammas, transcript: bool = False):
     pts = np.zeros((count, 3 + 2 * self.k, PW), dtype=np.uint64)
     sc = np.zeros((count, 3, 4), dtype=np.uint64)
     V = np.zeros((count, self.m, PW), dtype=np.uint64)
-    fn = _lib.lib().bpp_range_prove_batch_fs if transcript else _lib.lib().bpp_range_prove_batch
-    check(fn(self.handle, _ptr(vals), _ptr(gm), count, _ptr(pts), _ptr(sc), _ptr(V)), "bpp_range_prove_batch")
+    if blind_key is not None and (not transcript or len(blind_key) != 32):
+        raise ValueError("blind_key: 32 bytes, transcript mode only")
+    if transcript:
+        check(_lib.lib().bpp_range_prove_batch_fs(self.handle, _ptr(vals), _ptr(gm), count, blind_key, index_base, _ptr(pts),
+                                                  _ptr(sc), _ptr(V)), "bpp_range_prove_batch_fs")
+    else:
+        check(_lib.lib().bpp_range_prove_batch(self.handle, _ptr(vals), _ptr(gm), count, _ptr(pts), _ptr(sc), _ptr(V)),
+              "bpp_range_prove_batch")
     return pts, sc, V
 
 
@@ -625,10 +636,13 @@ def _engine_prover_workspace_bytes(self, count: int) -> int:
 
 def _engine_prove_batch_device(self, d_values: int, d_gammas: int, count: int, d_out_points: int, d_out_scalars: int,
                                d_out_V: int, d_workspace: int, workspace_bytes: int, stream: int = 0,
-                               transcript: bool = False, d_out_challenges: int = 0):
-    """prove_batch with every buffer in HBM (raw device pointers), asynchronous on `stream`."""
+                               transcript: bool = False, d_out_challenges: int = 0, blind_key: bytes = None,
+                               index_base: int = 0, d_blinding: int = 0):
+    """prove_batch with every buffer in HBM (raw device pointers), asynchronous on `stream`.  Transcript mode: blinding
+    from blind_key (32 bytes) / d_blinding (count x (5 + 2k) scalars on the device), else the reference's literals."""
     if transcript:
-        check(_lib.lib().bpp_range_prove_batch_fs_device(self.handle, d_values, d_gammas, count, d_out_points,
+        check(_lib.lib().bpp_range_prove_batch_fs_device(self.handle, d_values, d_gammas, count, blind_key, index_base,
+                                                         d_blinding or None, d_out_points,
                                                          d_out_scalars, d_out_V or None, d_out_challenges or None,
                                                          d_workspace, workspace_bytes, stream or None),
               "bpp_range_prove_batch_fs_device")
@@ -646,6 +660,12 @@ BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device
 BatchVerifier.derive_challenges_device = _verifier_derive_challenges_device
 BatchVerifier.sum_partials_device = _verifier_sum_partials_device
+def _verifier_set_subgroup_check(self, on: bool):
+    """wire points outside the prime-order subgroup count as invalid points (include/bpp_amd.h); off by default"""
+    check(_lib.lib().bpp_verifier_set_subgroup_check(self.handle, 1 if on else 0), "bpp_verifier_set_subgroup_check")
+
+
+BatchVerifier.set_subgroup_check = _verifier_set_subgroup_check
 BatchVerifier.set_profiling = _verifier_set_profiling
 BatchVerifier.profile = _verifier_profile
 

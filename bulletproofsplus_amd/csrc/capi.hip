@@ -21,9 +21,54 @@ extern "C" int bpp_init(int curve_id, int device, bpp_ctx** out_ctx) {
     *out_ctx = new bpp_ctx{curve_id, device};
     return BPP_OK;
 }
+// ---- the literal single-call API, second call onwards: a small-table verifier per public key -------------------
+// RangeProof::verify (src/range/mod.rs:57-78) takes the public key with every call and the reference pays the whole
+// naive MulVec each time.  bpp_range_verify does the same on the FIRST call with a key (the data-parallel naive MulVec,
+// no setup); a key that comes back gets a verifier with narrow window tables (c = 8: built in milliseconds, < 1 GB at
+// n m = 1024) that later calls with the same key run through -- the batch verifier's pass at count = 1.  Entries are
+// found by a 64-bit hash of (curve, n, m, g, h, G, H) and CONFIRMED by comparing the key bytes, so a hash collision can
+// never make a proof verify against another key's generators.  At most VCACHE_MAX verifiers, least recently used out.
+namespace {
+constexpr size_t VCACHE_MAX = 4;
+constexpr int VCACHE_WINDOW = 8;
+struct VerifyCacheEntry {
+    uint64_t hash = 0;
+    size_t n = 0, m = 0;
+    std::vector<uint64_t> key;   // gh | G | H as handed in
+    bpp_verifier* v = nullptr;   // null: seen once, tables not built yet
+    DevBuf pts, sc, ok, ws;      // count = 1 buffers of the pass
+    uint64_t stamp = 0;
+};
+struct VerifyCache {
+    std::vector<VerifyCacheEntry*> e;
+    uint64_t clock = 0;
+    ~VerifyCache() {
+        for (VerifyCacheEntry* x : e) {
+            delete x->v;
+            delete x;
+        }
+    }
+};
+inline uint64_t key_hash(int curve, size_t n, size_t m, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t pw) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)curve << 48) ^ ((uint64_t)n << 24) ^ (uint64_t)m;
+    auto mix = [&](const uint64_t* p, size_t words) {
+        for (size_t i = 0; i < words; i++) {
+            h ^= p[i];
+            h *= 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+        }
+    };
+    mix(gh, 2 * pw);
+    mix(G, n * m * pw);
+    mix(H, n * m * pw);
+    return h;
+}
+}  // namespace
+
 extern "C" void bpp_destroy(bpp_ctx* ctx) {
     if (!ctx) return;
     for (hipEvent_t e : ctx->msm_events) (void)hipEventDestroy(e);
+    delete static_cast<VerifyCache*>(ctx->verify_cache);
     delete ctx;
 }
 
@@ -153,9 +198,80 @@ extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t
                                 const uint64_t* V) {
     if (!ctx || !gh || !G || !H || !proof_points || !proof_scalars || !V) return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    return dispatch(ctx->curve, [&](auto cv) -> int {
-        return MsmImpl<decltype(cv)>::range_verify_single(gh, G, H, n, m, proof_points, k, proof_scalars, V);
-    });
+    auto naive = [&]() -> int {
+        return dispatch(ctx->curve, [&](auto cv) -> int {
+            return MsmImpl<decltype(cv)>::range_verify_single(gh, G, H, n, m, proof_points, k, proof_scalars, V);
+        });
+    };
+    const size_t mn = n * m;
+    if (n == 0 || m == 0 || n > VS_MAXN || m > VS_MAXM || (mn & (mn - 1)) || ctx->verify_cache_off) return naive();
+    const size_t pw = (size_t)bpp_point_words(ctx->curve);
+    if (!ctx->verify_cache) ctx->verify_cache = new VerifyCache();
+    VerifyCache& vc = *static_cast<VerifyCache*>(ctx->verify_cache);
+    const uint64_t h = key_hash(ctx->curve, n, m, gh, G, H, pw);
+    const size_t kw = (2 + 2 * mn) * pw;
+    VerifyCacheEntry* hit = nullptr;
+    for (VerifyCacheEntry* x : vc.e)
+        if (x->hash == h && x->n == n && x->m == m && std::memcmp(x->key.data(), gh, 2 * pw * 8) == 0 &&
+            std::memcmp(x->key.data() + 2 * pw, G, mn * pw * 8) == 0 &&
+            std::memcmp(x->key.data() + (2 + mn) * pw, H, mn * pw * 8) == 0)
+            hit = x;
+    if (!hit) {   // first sight of this key: remember it, answer by the naive MulVec
+        if (vc.e.size() >= VCACHE_MAX) {
+            size_t old = 0;
+            for (size_t i = 1; i < vc.e.size(); i++)
+                if (vc.e[i]->stamp < vc.e[old]->stamp) old = i;
+            delete vc.e[old]->v;
+            delete vc.e[old];
+            vc.e.erase(vc.e.begin() + old);
+        }
+        VerifyCacheEntry* x = new VerifyCacheEntry();
+        x->hash = h;
+        x->n = n;
+        x->m = m;
+        x->key.resize(kw);
+        std::memcpy(x->key.data(), gh, 2 * pw * 8);
+        std::memcpy(x->key.data() + 2 * pw, G, mn * pw * 8);
+        std::memcpy(x->key.data() + (2 + mn) * pw, H, mn * pw * 8);
+        x->stamp = ++vc.clock;
+        vc.e.push_back(x);
+        return naive();
+    }
+    hit->stamp = ++vc.clock;
+    if (!hit->v) {   // the key came back: build its tables (an invalid generator or no memory: stay with the naive path)
+        bpp_verifier* v = nullptr;
+        int rc = bpp_verifier_create(ctx, gh, G, H, n, m, VCACHE_WINDOW, &v);
+        if (rc) return naive();
+        const size_t wsb = bpp_verifier_workspace_bytes(v, 1);
+        if (hit->pts.alloc(v->s.NV * pw * 8) != hipSuccess || hit->sc.alloc(96) != hipSuccess ||
+            hit->ok.alloc(4) != hipSuccess || hit->ws.alloc(wsb) != hipSuccess) {
+            delete v;
+            return naive();
+        }
+        hit->v = v;
+    }
+    bpp_verifier* v = hit->v;
+    if (k != v->s.k) return BPP_VERIFICATION_ERROR;   // wip.rs:335-337
+    // record [A, wip.A, wip.B, L.., R.., V..]
+    HIPCHK(hipMemcpyAsync(hit->pts.p, proof_points, (3 + 2 * k) * pw * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(static_cast<uint8_t*>(hit->pts.p) + (3 + 2 * k) * pw * 8, V, m * pw * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(hit->sc.p, proof_scalars, 96, hipMemcpyHostToDevice, nullptr));
+    int rc = bpp_verifier_run(v, static_cast<const uint64_t*>(hit->pts.p), static_cast<const uint64_t*>(hit->sc.p), 1, nullptr,
+                              hit->ok.u32(), hit->ws.p, hit->ws.bytes, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    uint32_t verdict = 1;
+    HIPCHK(hipMemcpy(&verdict, hit->ok.p, 4, hipMemcpyDeviceToHost));
+    return verdict ? BPP_VERIFICATION_ERROR : BPP_OK;
+}
+
+extern "C" int bpp_set_verify_cache(bpp_ctx* ctx, int on) {
+    if (!ctx) return fail(BPP_E_ARG, "null argument");
+    ctx->verify_cache_off = on == 0;
+    if (!on) {
+        delete static_cast<VerifyCache*>(ctx->verify_cache);
+        ctx->verify_cache = nullptr;
+    }
+    return BPP_OK;
 }
 
 extern "C" int bpp_range_prove(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
@@ -230,12 +346,14 @@ extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, co
 }
 
 extern "C" int bpp_range_prove_batch_fs(bpp_verifier* engine, const uint64_t* v, const uint64_t* gamma, size_t count,
-                                        uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
+                                        const uint8_t* blind_key, uint64_t index_base, uint64_t* out_points,
+                                        uint64_t* out_scalars, uint64_t* out_V) {
     if (!engine || !v || !gamma || !out_points || !out_scalars) return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
     HIPCHK(hipSetDevice(engine->ctx.device));
     return dispatch(engine->ctx.curve, [&](auto cv) -> int {
-        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V, true);
+        return VerifyImpl<decltype(cv)>::prove_batch(engine, v, gamma, count, out_points, out_scalars, out_V, true, blind_key,
+                                                     index_base);
     });
 }
 
@@ -251,7 +369,9 @@ extern "C" size_t bpp_prover_workspace_bytes(const bpp_verifier* engine, size_t 
 
 static int prove_batch_device_common(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma, size_t count,
                                      uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
-                                     uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, void* stream) {
+                                     uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, void* stream,
+                                     const uint8_t* blind_key = nullptr, uint64_t index_base = 0,
+                                     const uint64_t* d_blinding = nullptr) {
     if (!engine || !d_v || !d_gamma || !d_out_points || !d_out_scalars || !d_workspace)
         return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
@@ -259,7 +379,7 @@ static int prove_batch_device_common(bpp_verifier* engine, const uint64_t* d_v, 
     return dispatch(engine->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::prove_batch_device(engine, d_v, d_gamma, count, d_out_points, d_out_scalars,
                                                             d_out_V, fs, d_out_challenges, d_workspace, workspace_bytes,
-                                                            static_cast<hipStream_t>(stream));
+                                                            static_cast<hipStream_t>(stream), blind_key, index_base, d_blinding);
     });
 }
 
@@ -271,11 +391,12 @@ extern "C" int bpp_range_prove_batch_device(bpp_verifier* engine, const uint64_t
 }
 
 extern "C" int bpp_range_prove_batch_fs_device(bpp_verifier* engine, const uint64_t* d_v, const uint64_t* d_gamma,
-                                               size_t count, uint64_t* d_out_points, uint64_t* d_out_scalars,
+                                               size_t count, const uint8_t* blind_key, uint64_t index_base,
+                                               const uint64_t* d_blinding, uint64_t* d_out_points, uint64_t* d_out_scalars,
                                                uint64_t* d_out_V, uint64_t* d_out_challenges, void* d_workspace,
                                                size_t workspace_bytes, void* stream) {
     return prove_batch_device_common(engine, d_v, d_gamma, count, d_out_points, d_out_scalars, d_out_V, true,
-                                     d_out_challenges, d_workspace, workspace_bytes, stream);
+                                     d_out_challenges, d_workspace, workspace_bytes, stream, blind_key, index_base, d_blinding);
 }
 
 // ---- combined batch check ------------------------------------------------------------------------------
@@ -330,6 +451,12 @@ extern "C" int bpp_verifier_derive_challenges(bpp_verifier* v, const uint64_t* d
         return VerifyImpl<decltype(cv)>::derive_challenges(v, d_points, count, d_challenges,
                                                            static_cast<hipStream_t>(stream));
     });
+}
+
+extern "C" int bpp_verifier_set_subgroup_check(bpp_verifier* v, int on) {
+    if (!v) return fail(BPP_E_ARG, "null argument");
+    v->check_subgroup = on != 0;
+    return BPP_OK;
 }
 
 extern "C" int bpp_verifier_set_profiling(bpp_verifier* v, int on) {
@@ -410,12 +537,12 @@ extern "C" int bpp_points_decompress(bpp_ctx* ctx, const uint8_t* in, size_t n, 
 }
 
 extern "C" int bpp_points_decompress_device(bpp_ctx* ctx, const void* d_in, size_t n, uint64_t* d_points, uint32_t* d_ok,
-                                            void* stream) {
+                                            int check_subgroup, void* stream) {
     if (!ctx || (n && (!d_in || !d_points || !d_ok))) return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
     return dispatch(ctx->curve, [&](auto cv) -> int {
         return CodecImpl<decltype(cv)>::decompress_device(static_cast<const uint8_t*>(d_in), n, d_points, d_ok,
-                                                          static_cast<hipStream_t>(stream));
+                                                          static_cast<hipStream_t>(stream), check_subgroup != 0);
     });
 }
 
@@ -438,7 +565,9 @@ extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t*
     HIPCHK(dws.alloc(wsb));
     HIPCHK(hipMemcpy(db.p, records, npts * cb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ds.p, scalars, count * 3 * 32, hipMemcpyHostToDevice));
-    int rc = bpp_points_decompress_device(&v->ctx, db.p, npts, static_cast<uint64_t*>(dp.p), dk.u32(), nullptr);
+    // the one wire entry point for points of unknown origin besides the container: reject what is outside the prime-order
+    // group too (the verifier's GLV evaluation equals s * P only there, include/bpp_amd.h)
+    int rc = bpp_points_decompress_device(&v->ctx, db.p, npts, static_cast<uint64_t*>(dp.p), dk.u32(), 1, nullptr);
     if (rc) return rc;
     rc = bpp_verifier_run(v, static_cast<const uint64_t*>(dp.p), static_cast<const uint64_t*>(ds.p), count, nullptr,
                           dok.u32(), dws.p, wsb, nullptr, nullptr, nullptr);
@@ -447,7 +576,7 @@ extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t*
     HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(bad.data(), dk.p, npts * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < npts; i++)
-        if (bad[i]) out_ok[i / v->s.NV] = 1;   // a malformed encoding rejects its proof (ProofError::FormatError's role)
+        if (bad[i]) out_ok[i / v->s.NV] = BPP_FORMAT_ERROR;   // a malformed encoding / a point outside the group: ProofError::FormatError
     // ... and so does a non-canonical scalar (r', s' or delta' >= the group order): a serialized proof has one encoding
     dispatch(v->ctx.curve, [&](auto cv) -> int {
         using Fr = typename decltype(cv)::Fr;
@@ -461,7 +590,7 @@ extern "C" int bpp_range_verify_batch_compressed(bpp_verifier* v, const uint8_t*
                     break;
                 }
             }
-            if (!lt) out_ok[i / 3] = 1;
+            if (!lt) out_ok[i / 3] = BPP_FORMAT_ERROR;
         }
         return BPP_OK;
     });

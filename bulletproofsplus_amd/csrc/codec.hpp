@@ -33,29 +33,33 @@ constexpr int compressed_bytes() {
 }
 
 // a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4; the caller checks the result by squaring.
-// Fixed 4-bit windows over the public constant P::SQRTW, most significant first: 14 products for the table a^2..a^15
-// (a local array the window digit indexes: it lives in private memory, not in registers), then four squarings and at
-// most one product per window -- 378 S + 95 + 14 M for BLS12-381 against 378 S + 228 M bit by bit ((p+1)/4 has 229 one
-// bits), 253 S + 78 M against 253 S + 246 M for secp256k1.
+// Fixed 2-bit windows over the public constant P::SQRTW, most significant first, with the three table entries a, a^2,
+// a^3 in REGISTERS: the exponent is the same in every lane, so the window digit is wave-uniform and the entry is picked
+// by uniform branches.  (A 4-bit table -- 14 + 95 products instead of 2 + 142 for BLS12-381 -- is a local array that
+// the digit indexes: it lived in scratch memory and made the decoder run at 73 % of the multiplier's rate.)
 template <class P>
 BPP_HD Fe<P> fe_sqrt_3mod4(const Fe<P>& a) {
-    Fe<P> tbl[16];
-    tbl[0] = Fe<P>::one();
-    tbl[1] = a;
-    for (int i = 2; i < 16; i++) tbl[i] = fe_mul(tbl[i - 1], a);
+    const Fe<P> a2 = fe_sqr(a);
+    const Fe<P> a3 = fe_mul(a2, a);
     Fe<P> acc = Fe<P>::one();
     bool started = false;
-    for (int w = P::N * 8 - 1; w >= 0; w--) {
-        const uint32_t d = (P::SQRTW[w >> 3] >> ((w & 7) * 4)) & 15u;
+    for (int w = P::N * 16 - 1; w >= 0; w--) {
+        const uint32_t d = (P::SQRTW[w >> 4] >> ((w & 15) * 2)) & 3u;
         if (started) {
-            acc = fe_sqr(acc);
-            acc = fe_sqr(acc);
             acc = fe_sqr(acc);
             acc = fe_sqr(acc);
         }
         if (d) {
-            acc = started ? fe_mul(acc, tbl[d]) : tbl[d];
-            started = true;
+            if (!started) {
+                acc = d == 1 ? a : (d == 2 ? a2 : a3);
+                started = true;
+            } else if (d == 1) {
+                acc = fe_mul(acc, a);
+            } else if (d == 2) {
+                acc = fe_mul(acc, a2);
+            } else {
+                acc = fe_mul(acc, a3);
+            }
         }
     }
     return acc;
@@ -114,8 +118,9 @@ __global__ void __launch_bounds__(128) k_points_compress(const uint32_t* __restr
 // compressed bytes -> wire point at w (2N + 2 words).  false: malformed (bad flags, x >= p, x not on the curve, not a
 // ristretto255 encoding; with check_subgroup also: outside the prime-order subgroup) -- w then holds infinity, so that
 // a consumer that ignores the verdict still sees a valid wire point.
-template <class C>
-__device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __restrict__ w, bool check_subgroup) {
+template <class C, bool CHECK_SUBGROUP>
+__device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __restrict__ w) {
+    constexpr bool check_subgroup = CHECK_SUBGROUP;
     using P = typename C::Fp;
     using F = Fe<P>;
     constexpr int N = P::N;
@@ -186,7 +191,7 @@ __device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __rest
             y = fe_neg(y);
             fe_to_canonical(y, yw);
         }
-        if (check_subgroup) {
+        if constexpr (check_subgroup) {
             Aff<C> a;
             a.x = xm;
             a.y = y;
@@ -210,7 +215,9 @@ __global__ void __launch_bounds__(64, 2) k_points_decompress(const uint8_t* __re
     constexpr int N = C::Fp::N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    ok[i] = point_decompress<C>(in + i * compressed_bytes<C>(), wire + i * (2 * N + 2), check_subgroup != 0) ? 0u : 1u;
+    const bool good = check_subgroup ? point_decompress<C, true>(in + i * compressed_bytes<C>(), wire + i * (2 * N + 2))
+                                     : point_decompress<C, false>(in + i * compressed_bytes<C>(), wire + i * (2 * N + 2));
+    ok[i] = good ? 0u : 1u;
 }
 
 // ---- the proof container on the device (layout: include/bpp_amd.h "serialized proofs") ---------------------------
@@ -238,7 +245,9 @@ __global__ void __launch_bounds__(64, 2) k_container_decode(VerifyShape s, const
     const uint32_t npp = 3 + 2 * s.k;
     const uint8_t* rec = proofs + p * container_bytes<C>(s.k);
     const uint8_t* src = t < npp ? rec + CONTAINER_HDR + (size_t)t * CB : commitments + (p * s.m + (t - npp)) * CB;
-    bool good = point_decompress<C>(src, records + i * (2 * N + 2), true);
+    // the G1 membership test is a kernel of its own (k_records_subgroup below): two chains of 64 doublings beside the
+    // square root's window table in one kernel cost 256 VGPRs and scratch
+    bool good = point_decompress<C, false>(src, records + i * (2 * N + 2));
     if (t == 0) {
         const uint8_t hdr[CONTAINER_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)C::ID, (uint8_t)s.n, (uint8_t)s.m, (uint8_t)s.k, 0, 0, 0};
         for (uint32_t b = 0; b < CONTAINER_HDR; b++) good = good && rec[b] == hdr[b];
@@ -253,6 +262,25 @@ __global__ void __launch_bounds__(64, 2) k_container_decode(VerifyShape s, const
         }
     }
     if (!good) atomicOr(status + p, 1u);
+}
+
+// One lane per decoded record point: outside the prime-order subgroup (BLS12-381 G1: csrc/ec.hpp aff_in_prime_subgroup) =>
+// the proof's status word is raised and the point replaced by infinity.  A no-op launch on the other curves.
+template <class C>
+__global__ void __launch_bounds__(64, 2) k_records_subgroup(uint32_t* __restrict__ records, uint32_t* __restrict__ status,
+                                                            uint32_t per_proof, size_t npoints) {
+    using P = typename C::Fp;
+    constexpr int N = P::N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    uint32_t* w = records + i * (2 * N + 2);
+    if (w[2 * N] | w[2 * N + 1]) return;   // infinity
+    Aff<C> a;
+    a.x = fe_from_canonical<P>(w);
+    a.y = fe_from_canonical<P>(w + N);
+    if (aff_in_prime_subgroup(a)) return;
+    for (int t = 0; t < 2 * N + 2; t++) w[t] = t == 2 * N ? 1u : 0u;
+    atomicOr(status + i / per_proof, 1u);
 }
 
 // ok[p] = BPP_FORMAT_ERROR where the decoder rejected proof p: ProofError::FormatError takes precedence over the

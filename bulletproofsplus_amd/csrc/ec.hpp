@@ -306,8 +306,8 @@ BPP_HD Xyzz<C> xyzz_madd(const Xyzz<C>& p, const Aff<C>& q) {
 // that consumes q.y, and the exceptional cases are detected AFTER the fact from the new ZZ (ZZ3 = ZZ * Pp^2
 // vanishes iff the x-coordinates agree), so the common path carries one zero test instead of five.
 // q: canonical affine coordinates (x, y < p; x = y = 0 is infinity), as the tables and proof points hold them.
-// Invariants of the accumulator between calls (multiples of p, checked by tests/test_lazy_bounds.py with the
-// worst case of every step): X < 6p, Y <= 2p, ZZ, ZZZ < 1.1p; every product below has alpha * beta <= 40,
+// Invariants of the accumulator between calls (multiples of p, checked on the host by tests/host/lazy_host_test.cpp --
+// random walks and an accumulator built AT the stated bounds -- run by tests/test_host_arith_cpu.py): X < 6p, Y <= 2p, ZZ, ZZZ < 1.1p; every product below has alpha * beta <= 40,
 // far under HEADROOM = R / p >= 630, so every Montgomery product comes out < 1.07 p.
 template <class C>
 BPP_HD void xyzz_madd_lazy(Xyzz<C>& p, const Aff<C>& q, bool neg) {
@@ -504,6 +504,100 @@ BPP_HD void glv_split(const uint32_t* k, uint32_t* k1, uint32_t* k2) {
     for (int t = 0; t < 4; t++) {
         k1[t] = rem[t];
         k2[t] = q[t];
+    }
+}
+
+// Which curves split scalars with an endomorphism: BLS12-381 G1 ([z^2] P = (beta x, -y), above) and secp256k1
+// ([lambda] P = (beta x, y)); the Edwards instantiation has none.
+template <class C>
+constexpr bool curve_has_glv() {
+    return C::ID == 0 || C::ID == 1;
+}
+// the y-coordinate of the endomorphism image changes sign (BLS12-381: the image under [z^2] is -phi(P))
+template <class C>
+constexpr bool glv_image_negates_y() {
+    return C::ID == 0;
+}
+
+// k = (+-k1) + (+-k2) * mu for the curve's endomorphism eigenvalue mu (z^2 on BLS12-381 G1, lambda on secp256k1):
+// magnitudes k1, k2 < 2^128 (4 words each) and their signs.  k: 8 canonical words, < r.
+// secp256k1 (Gallant-Lambert-Vanstone with the lattice basis libsecp256k1 documents; constants and bounds checked in
+// tools/gen_constants.py, the function itself against Python integers by tests/host/glv_host_test.cpp):
+//   c1 = round(k g1 / 2^384), c2 = round(k g2 / 2^384);  k2 = c1 (-b1) + c2 (-b2), k1 = k - k2 lambda  (mod n);
+//   a half above n / 2 stands for its negative.
+template <class C>
+BPP_HD void glv_split_signed(const uint32_t* k, uint32_t* k1, uint32_t* k2, bool& neg1, bool& neg2) {
+    if constexpr (C::ID == 0) {
+        glv_split<C>(k, k1, k2);
+        neg1 = false;
+        neg2 = false;
+    } else {
+        using K = typename C::K;
+        using P = typename C::Fr;
+        using F = Fe<P>;
+        static_assert(C::ID == 1, "secp256k1");
+        auto mulshift384 = [&](const uint32_t* g, uint32_t* c) {   // c[0..8) = round(k g / 2^384) (< 2^128)
+            uint64_t lo = 0;
+            uint32_t hi = 0;
+            uint32_t prod[16];
+#pragma unroll
+            for (int col = 0; col < 16; col++) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int jx = col - i;
+                    if (jx < 0 || jx > 7) continue;
+                    const uint64_t pr = (uint64_t)k[i] * g[jx];
+                    lo += pr;
+                    hi += lo < pr ? 1u : 0u;
+                }
+                prod[col] = (uint32_t)lo;
+                lo = (lo >> 32) | ((uint64_t)hi << 32);
+                hi = 0;
+            }
+            uint32_t carry = prod[11] >> 31;   // bit 383: round to nearest
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint64_t x = (uint64_t)(t < 4 ? prod[12 + t] : 0u) + carry;
+                c[t] = (uint32_t)x;
+                carry = (uint32_t)(x >> 32);
+            }
+        };
+        auto konst = [](const uint32_t* limbs) {
+            F r;
+#pragma unroll
+            for (int i = 0; i < P::NL; i++) r.l[i] = limbs[i];
+            return r;
+        };
+        uint32_t c1[8], c2[8];
+        mulshift384(K::GLV_G1W, c1);
+        mulshift384(K::GLV_G2W, c2);
+        const F f2 = fe_add(fe_mul(fe_from_canonical<P>(c1), konst(K::GLV_MB1)), fe_mul(fe_from_canonical<P>(c2), konst(K::GLV_MB2)));
+        const F f1 = fe_sub(fe_from_canonical<P>(k), fe_mul(f2, konst(K::GLV_LAMBDA)));
+        auto take = [](const F& f, uint32_t* out, bool& neg) {
+            uint32_t w[8];
+            fe_to_canonical(f, w);
+            bool above = false;   // w > (n - 1) / 2 ?
+            for (int t = 7; t >= 0; t--) {
+                if (w[t] != P::HALFW[t]) {
+                    above = w[t] > P::HALFW[t];
+                    break;
+                }
+            }
+            neg = above;
+            if (above) {   // n - w
+                uint32_t borrow = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint64_t d = (uint64_t)P::MODW[t] - w[t] - borrow;
+                    w[t] = (uint32_t)d;
+                    borrow = (uint32_t)(d >> 63);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) out[t] = w[t];
+        };
+        take(f1, k1, neg1);
+        take(f2, k2, neg2);
     }
 }
 

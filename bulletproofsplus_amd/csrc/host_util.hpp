@@ -21,6 +21,10 @@ struct bpp_ctx {
     size_t msm_passes = 0;
     std::vector<hipEvent_t> msm_events;
     uint32_t msm_shape[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // of the last bpp_msm_device call: n, items, W, q, nwide, nbuckets, L, c
+    // the small-table verifiers bpp_range_verify keeps per public key (capi.hip, struct VerifyCache); owned by the
+    // context that bpp_init returned -- the copies inside verifiers never touch it
+    void* verify_cache = nullptr;
+    bool verify_cache_off = false;
 };   // (the events are destroyed by bpp_destroy: verifiers keep a COPY of their context)
 constexpr size_t BPP_MSM_SLOTS = 16;
 

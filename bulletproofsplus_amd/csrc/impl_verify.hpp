@@ -20,6 +20,9 @@ struct bpp_verifier {
     bpp::DevBuf challenges;  // default challenges
     bpp::TranscriptState tr0;   // transcript state after the domain, curve, (n, m) and generator digest
     size_t table_bytes = 0;
+    // bpp_verifier_set_subgroup_check: wire points outside the prime-order subgroup count as invalid points (off by
+    // default: the in-memory API takes points that are in the group by construction, as the reference's mcl values are)
+    bool check_subgroup = false;
     // optional per-stage HIP-event timing: one (begin, end) event pair per stage and remembered pass
     bool profiling = false;
     std::vector<hipEvent_t> events;  // BPP_PROFILE_SLOTS x BPP_NUM_STAGES x 2
@@ -200,7 +203,7 @@ struct VerifyImpl {
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
     // and nothing synchronises.  The batch is processed in chunks that reuse one workspace.
     struct ProveLayout {
-        size_t a, b, cG, cH, pwy, con, vps, part, part1, part2, vout, trst, ch, total;
+        size_t a, b, cG, cH, pwy, con, vps, part, part1, part2, vout, trst, ch, blind, total;
         size_t chunk;
         unsigned per;
     };
@@ -244,6 +247,8 @@ struct VerifyImpl {
         o += al(w.chunk * 32);                      // transcript states (Fiat-Shamir mode)
         w.ch = o;
         o += al(w.chunk * (size_t)(3 + s.k) * 32);  // ... and the challenge blocks when the caller does not want them
+        w.blind = o;
+        o += al(w.chunk * (size_t)pb_blind_elems(s.k) * 32);   // blinding scalars expanded from the caller's key
         w.total = o;
         return w;
     }
@@ -253,13 +258,19 @@ struct VerifyImpl {
     // fs = true : challenges from the transcript (transcript.hpp): A and the commitments first, then y, z; each round's
     //             L_t, R_t before e_t; wip.A, wip.B before e -- 3 + k smaller launches and the hashing steps between
     //             them.  d_out_challenges (count x (3 + k) scalars, may be null) receives [y, z, e, e_1..e_k].
+    // Blinding (alpha, r, s, delta, eta, d_L[t], d_R[t] per proof): d_blinding (count x (5 + 2k) canonical scalars), or
+    // blind_key (32 bytes, host) expanded on the device with the global proof index index_base + p (k_pb_blind), or --
+    // both null -- the reference's literals (range/mod.rs:94,256; wip.rs:94-95,175-178), whose proofs hide nothing.
     static int prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
                                   uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
-                                  uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st);
+                                  uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st,
+                                  const uint8_t* blind_key = nullptr, uint64_t index_base = 0,
+                                  const uint64_t* d_blinding = nullptr);
 
     // host buffers in, host buffers out
     static int prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
-                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs);
+                           uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs,
+                           const uint8_t* blind_key = nullptr, uint64_t index_base = 0);
 
     // d_partials: n partials as bpp_verifier_run_combined wrote them (jacobian + validity word each)
     static int sum_partials(const uint32_t* d_partials, size_t n, uint32_t* d_ok, hipStream_t st);
@@ -350,7 +361,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     HIPCHK(zero_words_async(w_bad, count * 4, st));
     HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
-                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV);
+                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV, v->check_subgroup ? 1u : 0u);
     HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
     // Lone batches (below): the tables of the proof points need the points only, not the scalars -- a chain of seven
     // additions and an inversion that nothing else waits for yet, so it runs on a side stream beside the (equally latency
@@ -463,6 +474,9 @@ int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, cons
     HIPCHK(zero_words_async(w_st, count * 4, st));
     hipLaunchKernelGGL(k_container_decode<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, s, d_proofs, d_commitments,
                        w_rec, w_sc, w_st, count);
+    if constexpr (C::ID == 0)   // cofactor > 1: membership of the prime-order subgroup
+        hipLaunchKernelGGL(k_records_subgroup<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, w_rec, w_st, s.NV,
+                           count * s.NV);
     HIPCHK(hipGetLastError());
     if (transcript) {
         int rc = derive_challenges(v, reinterpret_cast<const uint64_t*>(w_rec), count, w_ch, st);
@@ -511,7 +525,7 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     HIPCHK(zero_words_async(w_bad, count * 4, st));
     HIPCHK(zero_words_async(w_cs, (size_t)s.N * 32, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
-                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV);
+                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     {
@@ -557,10 +571,16 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
 template <class C>
 int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values, const uint64_t* d_gammas, size_t count,
                               uint64_t* d_out_points, uint64_t* d_out_scalars, uint64_t* d_out_V, bool fs,
-                              uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+                              uint64_t* d_out_challenges, void* d_workspace, size_t workspace_bytes, hipStream_t st,
+                              const uint8_t* blind_key, uint64_t index_base, const uint64_t* d_blinding) {
     const VerifyShape& s = v->s;
     const uint32_t k = s.k, m = s.m;
     const uint32_t nvp = pb_num_vps(k, m);
+    BlindKey bk;
+    for (int i = 0; i < 8; i++)
+        bk.w[i] = blind_key ? (uint32_t)blind_key[4 * i] | ((uint32_t)blind_key[4 * i + 1] << 8) |
+                                  ((uint32_t)blind_key[4 * i + 2] << 16) | ((uint32_t)blind_key[4 * i + 3] << 24)
+                            : 0u;
     const ProveLayout L = prove_layout(s, count);
     if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
     ProverConsts pc;
@@ -580,6 +600,14 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
         uint32_t* o_V = d_out_V ? reinterpret_cast<uint32_t*>(d_out_V) + base * (size_t)m * WW : W(L.vout);
         const uint64_t* vals = d_values + base * m;
         const uint32_t* gams = reinterpret_cast<const uint32_t*>(d_gammas) + base * (size_t)m * 8;
+        const uint32_t* blind = nullptr;   // this chunk's blinding scalars
+        if (d_blinding) {
+            blind = reinterpret_cast<const uint32_t*>(d_blinding) + base * (size_t)pb_blind_elems(k) * 8;
+        } else if (blind_key) {
+            hipLaunchKernelGGL(k_pb_blind<C>, dim3(cdiv(cnt * pb_blind_elems(k), 64)), dim3(64), 0, st, bk, index_base + base, k,
+                               W(L.blind), cnt);
+            blind = W(L.blind);
+        }
         // one MulVec launch over `sel` of every proof's virtual proofs, then their wire points into the records
         auto msm = [&](VpSel sel) {
             const size_t nv = cnt * sel.cnt;
@@ -596,12 +624,12 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
                                per * (FIXED_BLOCK / FOLD_GROUP / FOLD_GROUP2), o_pts, o_V, nv);
         };
         if (!fs) {
-            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, 0u, vals, gams,
+            hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_ALL, 0u, vals, gams,
                                v->challenges.u32(), 0u, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
             for (uint32_t t = 0; t < k; t++)
-                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_ALL, W(L.a),
+                hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, t, (uint32_t)PB_ALL, W(L.a),
                                    W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
-            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_ALL, W(L.a), W(L.b),
+            hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_ALL, W(L.a), W(L.b),
                                W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
             msm(VpSel{nvp, 0u, nvp, 1u});
             continue;
@@ -610,26 +638,26 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
                                           : W(L.ch);
         const uint32_t chs = (3 + k) * 8;
         const unsigned lanes = cdiv(cnt, 64);
-        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
+        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_PRE, 1u, vals, gams, o_ch,
                            chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
         msm(VpSel{nvp, 0u, 1u, 1u});              // A
         msm(VpSel{nvp, 2 * k + 3, m, 1u});        // V_0 .. V_{m-1}
         hipLaunchKernelGGL(k_pb_fs_yz<C>, dim3(lanes), dim3(64), 0, st, s, v->tr0, o_pts, o_V, W(L.trst), o_ch, cnt);
-        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
+        hipLaunchKernelGGL(k_pb_init<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_POST, 1u, vals, gams, o_ch,
                            chs, W(L.a), W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
         for (uint32_t t = 0; t < k; t++) {
-            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
+            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, t, (uint32_t)PB_PRE, W(L.a), W(L.b),
                                W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
             msm(VpSel{nvp, 1 + 2 * t, 2u, 1u});   // L_t, R_t
             hipLaunchKernelGGL(k_pb_fs_round<C>, dim3(lanes), dim3(64), 0, st, s, t, o_pts, W(L.trst), o_ch, W(L.con), cnt);
-            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, t, (uint32_t)PB_POST, W(L.a),
+            hipLaunchKernelGGL(k_pb_round<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, t, (uint32_t)PB_POST, W(L.a),
                                W(L.b), W(L.cG), W(L.cH), W(L.pwy), W(L.con), W(L.vps));
         }
-        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_PRE, W(L.a), W(L.b),
+        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_PRE, W(L.a), W(L.b),
                            W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
         msm(VpSel{nvp, 2 * k + 1, 2u, 1u});       // wip.A, wip.B
         hipLaunchKernelGGL(k_pb_fs_final<C>, dim3(lanes), dim3(64), 0, st, s, o_pts, W(L.trst), o_ch, W(L.con), cnt);
-        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, (uint32_t)PB_POST, W(L.a), W(L.b),
+        hipLaunchKernelGGL(k_pb_final<C>, dim3((unsigned)cnt), dim3(256), 0, st, s, pc, blind, (uint32_t)PB_POST, W(L.a), W(L.b),
                            W(L.cG), W(L.cH), W(L.con), W(L.vps), o_sc);
     }
     HIPCHK(hipGetLastError());
@@ -638,7 +666,8 @@ int VerifyImpl<C>::prove_batch_device(bpp_verifier* v, const uint64_t* d_values,
 
 template <class C>
 int VerifyImpl<C>::prove_batch(bpp_verifier* v, const uint64_t* values, const uint64_t* gammas, size_t count,
-                       uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs) {
+                       uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V, bool fs, const uint8_t* blind_key,
+                       uint64_t index_base) {
     const VerifyShape& s = v->s;
     const uint32_t k = s.k, m = s.m;
     hipStream_t st = nullptr;
@@ -654,7 +683,7 @@ int VerifyImpl<C>::prove_batch(bpp_verifier* v, const uint64_t* values, const ui
     HIPCHK(d_ws.alloc(L.total));
     rc = prove_batch_device(v, static_cast<const uint64_t*>(d_val.p), static_cast<const uint64_t*>(d_gam.p), count,
                             static_cast<uint64_t*>(d_pts.p), static_cast<uint64_t*>(d_sc.p),
-                            static_cast<uint64_t*>(d_V.p), fs, nullptr, d_ws.p, L.total, st);
+                            static_cast<uint64_t*>(d_V.p), fs, nullptr, d_ws.p, L.total, st, blind_key, index_base, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out_points, d_pts.p, count * (size_t)(3 + 2 * k) * WW * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out_scalars, d_sc.p, count * 96, hipMemcpyDeviceToHost, st));

@@ -41,13 +41,14 @@ constexpr unsigned VS_PB = 8;                 // proofs per block of k_vs_expand
 constexpr unsigned VS_BLOCK = VS_PB * 64;
 constexpr unsigned FIXED_BLOCK = 128;
 constexpr unsigned VAR_BLOCK = 64;
-// Proof-point MSM: signed 4-bit windows.  Plain: 65 windows of a 260-bit value (scalar + bias).  BLS12-381 splits every
-// scalar with the curve's endomorphism first (GLV: k = k1 + k2 z^2, [z^2] P = (beta x, -y); k_var_digits), so a point
-// contributes TWO 128-bit halves and there are 33 windows -- the same number of mixed additions (33 x 2 against 65),
-// but half the ~256 sequential doublings of the Horner stage, which is what a small batch waits for.
+// Proof-point MSM: signed 4-bit windows.  Plain: 65 windows of a 260-bit value (scalar + bias).  BLS12-381 and secp256k1
+// split every scalar with the curve's endomorphism first (GLV, ec.hpp glv_split_signed: k = +-k1 +- k2 mu, the image of P
+// under [mu] is (beta x, -+y); k_var_digits), so a point contributes TWO 128-bit halves and there are 33 windows -- the
+// same number of mixed additions (33 x 2 against 65), but half the ~256 sequential doublings of the Horner stage, which
+// is what a small batch waits for.  edwards25519 has no such endomorphism and keeps 65 windows.
 template <class C>
 constexpr bool var_glv() {
-    return C::ID == 0;
+    return curve_has_glv<C>();
 }
 template <class C>
 constexpr uint32_t var_windows() {
@@ -168,10 +169,11 @@ __device__ __forceinline__ Jac<C> block_reduce_jac(Jac<C> acc, uint32_t* lds) {
 // ---- wire <-> device images --------------------------------------------------------------------------
 
 // wire points -> affm.  per_group > 0: bad[i / per_group] is set when point i is invalid (coordinate
-// >= p or not on the curve); invalid points are replaced by infinity.
+// >= p or not on the curve; with check_subgroup also: outside the prime-order subgroup, ec.hpp
+// aff_in_prime_subgroup); invalid points are replaced by infinity.
 template <class C>
 __global__ void __launch_bounds__(128) k_points_from_wire(const uint32_t* __restrict__ wire, uint32_t* __restrict__ affm,
-                                   uint32_t* __restrict__ bad, size_t n, uint32_t per_group) {
+                                   uint32_t* __restrict__ bad, size_t n, uint32_t per_group, uint32_t check_subgroup = 0) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +182,8 @@ __global__ void __launch_bounds__(128) k_points_from_wire(const uint32_t* __rest
 #pragma unroll
     for (int t = 0; t < 2 * N + 2; t++) w[t] = wire[i * (2 * N + 2) + t];
     Aff<C> p;
-    const bool ok = aff_from_wire<C>(w, p);
+    bool ok = aff_from_wire<C>(w, p);
+    if (ok && check_subgroup) ok = aff_in_prime_subgroup<C>(p);
     if (!ok) {
         p = aff_inf<C>();
         if (bad) atomicOr(&bad[per_group ? i / per_group : 0], 1u);
@@ -1166,8 +1169,10 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
     // digit j of a value = nibble j of (value + 0x88..8) minus 8, stored biased (the nibble itself): 0..15, 8 means 0
     if constexpr (var_glv<C>()) {
         uint32_t rem[4], q[4];
-        glv_split<C>(k, rem, q);   // k = rem + q z^2, both < 2^128 (ec.hpp)
-        // 33 biased nibbles of each half: k1 at byte 0.., k2 at byte 33..
+        bool nh[2];
+        glv_split_signed<C>(k, rem, q, nh[0], nh[1]);   // k = +-rem +- q mu, both < 2^128 (ec.hpp)
+        // 33 biased nibbles of each half: k1 at byte 0.., k2 at byte 33..; a negative half stores the negated digits
+        // (16 - nibble: the digit -(nibble - 8), still |digit| <= 8)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             uint32_t w[5];
@@ -1180,7 +1185,8 @@ __global__ void __launch_bounds__(256) k_var_digits(VerifyShape s, const uint32_
             }
 #pragma unroll
             for (int j = 0; j < 33; j++) {
-                const uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
+                uint32_t nib = (w[j >> 3] >> ((j & 7) * 4)) & 15u;
+                if (nh[h]) nib = 16u - nib;
                 const int byte = h * 33 + j;
                 out[byte >> 2] |= nib << ((byte & 3) * 8);
             }
@@ -1287,10 +1293,10 @@ __global__ void __launch_bounds__(VAR_BLOCK, BPP_VAR_WAVES) k_var_windows(Verify
         }
         bool neg = d < 0;
         if constexpr (var_glv<C>()) {
-            if (d && ((h0 + u % HL) & 1u)) {   // [z^2] T = (beta x, -y); infinity (x = y = 0) stays infinity
+            if (d && ((h0 + u % HL) & 1u)) {   // [mu] T = (beta x, -+y); infinity (x = y = 0) stays infinity
                 cur.x = fe_mul(cur.x, beta);
                 fe_cond_sub_p(cur.x);
-                neg = !neg;
+                if (glv_image_negates_y<C>()) neg = !neg;
             }
         }
         if (d) xyzz_madd_lazy(acc, cur, neg);

@@ -6,10 +6,11 @@
 // finishes in one scalar-mult latency; this file is the path for N in the thousands and up: bpp_msm_device /
 // bpp_msm on big inputs.  Every buffer lives in HBM; nothing here synchronises with the host.
 //
-// Scalars.  On BLS12-381 every scalar is first split with G1's endomorphism (GLV, ec.hpp glv_split: k = k1 + k2 z^2,
-// both halves < 2^128, [z^2] P = (beta x, -y)): an input point becomes TWO items (P with k1, phi(P) with k2) of 128-bit
-// sub-scalars -- the same number of bucket additions, but half the windows, so half the buckets to reduce and half
-// the ~255 sequential doublings of the tail.  The other curves run one item of Fr::BITS bits per point.
+// Scalars.  On BLS12-381 and secp256k1 every scalar is first split with the curve's endomorphism (GLV, ec.hpp
+// glv_split_signed: k = +-k1 +- k2 mu, both halves < 2^128, [mu] P = (beta x, -+y)): an input point becomes TWO items
+// (P with k1, its image with k2) of 128-bit sub-scalars -- the same number of bucket additions, but half the windows, so
+// half the buckets to reduce and half the ~255 sequential doublings of the tail.  edwards25519 has no endomorphism and
+// runs one item of Fr::BITS bits per point.
 // Windows of MIXED width: W = ceil(bits / c) windows share the bits as evenly as they divide -- the low `nwide` windows
 // are q + 1 bits wide, the rest q (<= c) -- so that every window has about the same number of buckets and no window is
 // left with a handful of bits (a 2-bit top window would put a quarter of all points into each of its buckets).  All
@@ -50,7 +51,7 @@ namespace bpp {
 
 template <class C>
 constexpr bool pip_glv() {
-    return C::ID == 0;
+    return curve_has_glv<C>();
 }
 
 struct PipShape {
@@ -199,7 +200,7 @@ __device__ __forceinline__ Jac<C> wave_suffix_jac(Jac<C> x) {
 }
 
 // ---- points -----------------------------------------------------------------------------------------------
-// wire -> affm; items n..2n-1 (GLV): (beta x, -y), the image under [z^2].  bad[0] |= 1 for an invalid point
+// wire -> affm; items n..2n-1 (GLV): the image under the endomorphism, (beta x, -y) / (beta x, y).  bad[0] |= 1 for an invalid point
 // (replaced by infinity).
 template <class C>
 __global__ void __launch_bounds__(128) k_pip_points(PipShape s, const uint32_t* __restrict__ wire,
@@ -223,7 +224,7 @@ __global__ void __launch_bounds__(128) k_pip_points(PipShape s, const uint32_t* 
 #pragma unroll
             for (int t = 0; t < C::Fp::NL; t++) beta.l[t] = C::K::BETA[t];
             q.x = fe_mul(beta, p.x);
-            q.y = fe_neg(p.y);
+            if (glv_image_negates_y<C>()) q.y = fe_neg(p.y);
         }
         aff_stg<C>(affm + ((size_t)s.n + i) * 2 * N, q);
     }
@@ -249,9 +250,10 @@ __global__ void __launch_bounds__(256) k_pip_digits(PipShape s, const uint32_t* 
         }
     }
     uint32_t sub[2][8];
+    bool nh[2] = {false, false};   // a negative half: every digit changes sign
     if constexpr (pip_glv<C>()) {
         uint32_t k1[4], k2[4];
-        glv_split<C>(k, k1, k2);
+        glv_split_signed<C>(k, k1, k2, nh[0], nh[1]);
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             sub[0][t] = t < 4 ? k1[t] : 0u;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256) k_pip_digits(PipShape s, const uint32_t* 
             if (dg != 0) {
                 const uint32_t b = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
                 slot = atomicAdd(&counts[bb + b], 1u);
-                key = (b << 1) | (dg < 0 ? 1u : 0u);
+                key = (b << 1) | ((dg < 0) != nh[h] ? 1u : 0u);
             }
             keys[(size_t)j * s.items + e] = key;
             slots[(size_t)j * s.items + e] = slot;

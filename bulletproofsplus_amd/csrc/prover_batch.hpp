@@ -31,6 +31,63 @@ struct ProverConsts {
     uint32_t r, s, delta, eta; // wip.rs:175-178
 };
 
+// The reference's blinding values are literals, so its proofs hide nothing (with alpha, r, s, delta, eta, d_L, d_R known,
+// r', s', delta' give away the folded a, b and a linear combination of the gammas).  A caller that wants hiding proofs
+// supplies them per proof -- `blind`: [count][5 + 2k] canonical scalars [alpha, r, s, delta, eta, d_L[0..k), d_R[0..k)] --
+// either as a buffer of its own or expanded from a 32-byte secret key by k_pb_blind.  blind == nullptr: the literals.
+__host__ __device__ inline uint32_t pb_blind_elems(uint32_t k) { return 5 + 2 * k; }
+enum { PB_BL_ALPHA = 0, PB_BL_R = 1, PB_BL_S = 2, PB_BL_DELTA = 3, PB_BL_ETA = 4, PB_BL_DL = 5 };
+template <class P>
+__device__ __forceinline__ Fe<P> pb_blind(uint32_t literal, const uint32_t* __restrict__ blind, size_t p, uint32_t k,
+                                          uint32_t slot) {
+    if (!blind) return fe_from_u32<P>(literal);
+    uint32_t w[8];
+    ld_words<8>(blind + (p * pb_blind_elems(k) + slot) * 8, w);
+    return fe_from_canonical<P>(w);
+}
+// blind[p][slot] = (c0 + 2^256 c1) mod r,  c_h = SHA-256(key[32] || "bppb" || (index_base + p) as u64 LE || slot as u32 LE
+// || h as u32 LE) read as little-endian 256-bit integers; zero is replaced by one.  One lane per (proof, slot).
+struct BlindKey {
+    uint32_t w[8];   // the 32 key bytes as little-endian words
+};
+template <class C>
+__global__ void __launch_bounds__(64) k_pb_blind(BlindKey key, uint64_t index_base, uint32_t k,
+                                                 uint32_t* __restrict__ blind, size_t count) {
+    using P = typename C::Fr;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ne = pb_blind_elems(k);
+    if (i >= count * ne) return;
+    const uint64_t idx = index_base + i / ne;
+    const uint32_t slot = (uint32_t)(i % ne);
+    uint32_t c[16];
+    for (uint32_t h = 0; h < 2; h++) {
+        Sha256 s;
+        sha256_init(s);
+#pragma unroll
+        for (int t = 0; t < 8; t++) sha256_word_le(s, key.w[t]);
+        sha256_word_le(s, 0x62707062u);   // "bppb"
+        sha256_word_le(s, (uint32_t)idx);
+        sha256_word_le(s, (uint32_t)(idx >> 32));
+        sha256_word_le(s, slot);
+        sha256_word_le(s, h);
+        uint32_t dg[8];
+        sha256_final(s, dg);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const uint32_t be = dg[t];
+            c[8 * h + t] = (be >> 24) | ((be >> 8) & 0xff00u) | ((be << 8) & 0xff0000u) | (be << 24);
+        }
+    }
+    uint32_t w128[8] = {0, 0, 0, 0, 1, 0, 0, 0};
+    const Fe<P> f128 = fe_from_canonical<P>(w128);
+    const Fe<P> f256 = fe_mul(f128, f128);
+    Fe<P> x = fe_add(fe_from_canonical<P>(c), fe_mul(fe_from_canonical<P>(c + 8), f256));
+    if (x.is_zero()) x = Fe<P>::one();
+    uint32_t o[8];
+    fe_to_canonical(x, o);
+    st_words<8>(blind + i * 8, o);
+}
+
 // layout of the per-proof constants block (Fr elements, Montgomery, packed 8 words each)
 //   [0] yinv  [1] alpha_w  [2] y  [3] z  [4] e_final  [5 .. 5+k) e_t  [5+k .. 5+2k) e_t^-1
 __host__ __device__ inline uint32_t pb_consts_elems(uint32_t k) { return 5 + 2 * k; }
@@ -70,7 +127,7 @@ enum { PB_ALL = 0, PB_PRE = 1, PB_POST = 2 };
 // challenges: [y, z, e, e_1..e_k] (shared when ch_stride == 0).  fs: the round challenges are not known yet (only
 // y and z are read; e_t and e_t^-1 are filled in round by round by k_pb_fs_round).
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc, uint32_t phase, uint32_t fs,
+__global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc, const uint32_t* __restrict__ blind, uint32_t phase, uint32_t fs,
                                                  const uint64_t* __restrict__ values,
                                                  const uint32_t* __restrict__ gammas,
                                                  const uint32_t* __restrict__ challenges, uint32_t ch_stride,
@@ -108,7 +165,7 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
             pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 2 + (bit ? 0u : mn) + i) * 8, one_);
         }
         if (tid == 0) {
-            pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.alpha));
+            pb_st_canon<P>(vp0 + (size_t)fixed_term_index(s, 1) * 8, pb_blind<P>(pc.alpha, blind, p, k, PB_BL_ALPHA));
             for (uint32_t j = 0; j < m; j++) {
                 // commitment V_j = new(v as i32) g + gamma h            (range/prover.rs:34-40)
                 uint32_t w[8];
@@ -202,7 +259,7 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
         pb_st<P>(st_cH + (p * mn + i) * 8, one);
     }
     if (tid == 0) {
-        const F alpha = fe_from_u32<P>(pc.alpha);
+        const F alpha = pb_blind<P>(pc.alpha, blind, p, k, PB_BL_ALPHA);
         // alpha_hat = alpha + y^(mn+1) * sum_j pz_j gamma_j        (:172 / :366-376)
         F acc = F::zero();
         for (uint32_t j = 0; j < m; j++) {
@@ -218,7 +275,7 @@ __global__ void __launch_bounds__(256) k_pb_init(VerifyShape s, ProverConsts pc,
 // One folding round t (wip.rs:79-172) for every proof: emits the scalar arrays of L_t and R_t, then folds
 // a, b, cG, cH and alpha.  One block (256 threads) per proof.
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc, uint32_t t, uint32_t phase,
+__global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc, const uint32_t* __restrict__ blind, uint32_t t, uint32_t phase,
                                                   uint32_t* __restrict__ st_a, uint32_t* __restrict__ st_b,
                                                   uint32_t* __restrict__ st_cG, uint32_t* __restrict__ st_cH,
                                                   const uint32_t* __restrict__ st_pwy,
@@ -265,9 +322,9 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
     }
     if (tid == 0) {
         pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 0) * 8, redL[0]);
-        pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.d_L));
+        pb_st_canon<P>(vpL + (size_t)fixed_term_index(s, 1) * 8, pb_blind<P>(pc.d_L, blind, p, k, PB_BL_DL + t));
         pb_st_canon<P>(vpR + (size_t)fixed_term_index(s, 0) * 8, redR[0]);
-        pb_st_canon<P>(vpR + (size_t)fixed_term_index(s, 1) * 8, fe_from_u32<P>(pc.d_R));
+        pb_st_canon<P>(vpR + (size_t)fixed_term_index(s, 1) * 8, pb_blind<P>(pc.d_R, blind, p, k, PB_BL_DL + k + t));
     }
     // scalars of L_t and R_t over the ORIGINAL generators        (wip.rs:100-125)
     for (uint32_t j = tid; j < mn; j += blockDim.x) {
@@ -293,7 +350,8 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
     if (tid == 0) {
         // alpha += e^2 d_L + e^-2 d_R                                (wip.rs:171)
         F al = pb_ld<P>(consts + 1 * 8);
-        al = fe_add(al, fe_add(fe_mul(fe_sqr(e), fe_from_u32<P>(pc.d_L)), fe_mul(fe_sqr(einv), fe_from_u32<P>(pc.d_R))));
+        al = fe_add(al, fe_add(fe_mul(fe_sqr(e), pb_blind<P>(pc.d_L, blind, p, k, PB_BL_DL + t)),
+                           fe_mul(fe_sqr(einv), pb_blind<P>(pc.d_R, blind, p, k, PB_BL_DL + k + t))));
         pb_st<P>(consts + 1 * 8, al);
     }
     // fold the coefficient products (wip.rs:151-163 expressed on scalars)
@@ -315,7 +373,7 @@ __global__ void __launch_bounds__(256) k_pb_round(VerifyShape s, ProverConsts pc
 
 // After the k rounds: scalars of wip.A and wip.B, and r', s', delta'   (wip.rs:175-216)
 template <class C>
-__global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc, uint32_t phase,
+__global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc, const uint32_t* __restrict__ blind, uint32_t phase,
                                                   const uint32_t* __restrict__ st_a,
                                                   const uint32_t* __restrict__ st_b,
                                                   const uint32_t* __restrict__ st_cG,
@@ -331,7 +389,7 @@ __global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc
     const uint32_t nvp = pb_num_vps(k, s.m);
     uint32_t* vpA = vps + (p * nvp + 2 * k + 1) * (size_t)s.N * 8;
     uint32_t* vpB = vpA + (size_t)s.N * 8;
-    const F r = fe_from_u32<P>(pc.r), sc = fe_from_u32<P>(pc.s);
+    const F r = pb_blind<P>(pc.r, blind, p, k, PB_BL_R), sc = pb_blind<P>(pc.s, blind, p, k, PB_BL_S);
     if (phase != PB_POST)
         for (uint32_t j = tid; j < mn; j += blockDim.x) {
             pb_st_canon<P>(vpA + (size_t)fixed_term_index(s, 2 + j) * 8, fe_mul(r, pb_ld<P>(st_cG + (p * mn + j) * 8)));
@@ -340,7 +398,7 @@ __global__ void __launch_bounds__(256) k_pb_final(VerifyShape s, ProverConsts pc
     if (tid == 0) {
         const F y = pb_ld<P>(consts + 2 * 8), alpha = pb_ld<P>(consts + 1 * 8);
         const F a0 = pb_ld<P>(st_a + p * (size_t)mn * 8), b0 = pb_ld<P>(st_b + p * (size_t)mn * 8);
-        const F delta = fe_from_u32<P>(pc.delta), eta = fe_from_u32<P>(pc.eta);
+        const F delta = pb_blind<P>(pc.delta, blind, p, k, PB_BL_DELTA), eta = pb_blind<P>(pc.eta, blind, p, k, PB_BL_ETA);
         const F ry = fe_mul(r, y);
         if (phase != PB_POST) {
             const F rcbsca = fe_add(fe_mul(ry, b0), fe_mul(fe_mul(sc, y), a0));

@@ -91,6 +91,13 @@ BPP_HD void tr_append_point(Transcript& t, uint32_t tag, const uint32_t* wire) {
         for (int i = 0; i < 8; i++)
             w[i] = (uint32_t)enc[4 * i] | ((uint32_t)enc[4 * i + 1] << 8) | ((uint32_t)enc[4 * i + 2] << 16) | ((uint32_t)enc[4 * i + 3] << 24);
         tr_append_words(t, tag, w, 8);
+    } else if (wire[2 * N] | wire[2 * N + 1]) {
+        // ONE byte string per group element: aff_from_wire takes any non-zero flag words as infinity and ignores x, y,
+        // so what is hashed is the canonical image (zero coordinates, flag = 1), not the caller's bytes
+        uint32_t z[2 * N + 2];
+#pragma unroll
+        for (int i = 0; i < 2 * N + 2; i++) z[i] = i == 2 * N ? 1u : 0u;
+        tr_append_words(t, tag, z, 2 * N + 2);
     } else {
         tr_append_words(t, tag, wire, 2 * N + 2);
     }
@@ -185,7 +192,8 @@ inline void tr_initial_state(uint32_t n, uint32_t m, const uint32_t* pk_wire, si
             rist_encode(jac_from_aff(a), enc);
             sha256_update(s, enc, 32);
         } else {
-            for (int i = 0; i < WW; i++) sha256_word_le(s, w[i]);
+            const bool inf = (w[2 * N] | w[2 * N + 1]) != 0;   // canonical image of infinity, as in tr_append_point
+            for (int i = 0; i < WW; i++) sha256_word_le(s, inf ? (i == 2 * N ? 1u : 0u) : w[i]);
         }
     }
     uint32_t pkd[8];

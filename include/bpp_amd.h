@@ -145,7 +145,14 @@ int bpp_wip_fold_round(bpp_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t *G, uint
 
 /* RangeProof::verify (src/range/mod.rs:57-78 -> verify_single :189-238 + wip verify
  * src/weighted_inner_product_proof.rs:238-328, or verify_multiple :405-510).
- * proof_points as written by bpp_range_prove with k rounds.  Returns 0 / 1 / negative. */
+ * proof_points as written by bpp_range_prove with k rounds.  Returns 0 / 1 / negative.
+ * The reference takes the public key with every call and pays the whole naive MulVec each time; so does the FIRST call
+ * here with a given key (data-parallel naive MulVec, no setup).  When the same key comes back the context builds a
+ * verifier with narrow window tables for it (c = 8: milliseconds to build, < 1 GB at n m = 1024) and that and later
+ * calls run the batch verifier's pass at count = 1.  A cached entry is found by hash and confirmed by comparing the
+ * key bytes; at most four keys, least recently used out; bpp_set_verify_cache(ctx, 0) switches the mechanism off and
+ * frees it.  Verdicts do not depend on which path ran (tests/test_gpu_round3.py). */
+int bpp_set_verify_cache(bpp_ctx *ctx, int on);
 int bpp_range_verify(bpp_ctx *ctx, const uint64_t *gh, const uint64_t *G, const uint64_t *H, size_t n,
                      size_t m, const uint64_t *proof_points, size_t k, const uint64_t *proof_scalars,
                      const uint64_t *V);
@@ -247,17 +254,45 @@ int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n,
  *   d_points     : count x (3 + 2k + m) wire points, as for bpp_verifier_run
  *   d_challenges : count x (3 + k) scalars (out)
  * bpp_range_prove_batch_fs is the prover under the same transcript (round t + 1 waits for L_t, R_t); outputs as
- * bpp_range_prove_batch_device. */
+ * bpp_range_prove_batch_device.  An infinity enters the transcript as its canonical image (zero coordinates, flag = 1)
+ * whatever non-zero flag word the caller wrote: one byte string per group element. */
 int bpp_verifier_derive_challenges(bpp_verifier *v, const uint64_t *d_points, size_t count, uint64_t *d_challenges,
                                    void *stream);
-/* host buffers, as bpp_range_prove_batch */
+/* Blinding.  The reference's blinding values are literals (alpha = 7 / 33, range/mod.rs:94,256; d_L = 4, d_R = 5,
+ * wip.rs:94-95; r, s, delta, eta = 33, 44, 88, 123, wip.rs:175-178), so a proof made with them is sound but NOT hiding:
+ * with those known, r', s', delta' give away the folded a, b and a linear combination of the gammas (for m = 1: gamma
+ * itself, hence v).  That is kept, bit for bit, in the reference-parity calls (bpp_range_prove, bpp_range_prove_batch*).
+ * Under the transcript the caller supplies the blinding: per proof alpha, r, s, delta, eta and d_L[t], d_R[t] for each of
+ * the k rounds, one of
+ *   d_blinding : count x (5 + 2k) canonical scalars on the device [alpha, r, s, delta, eta, d_L[0..k), d_R[0..k)]; or
+ *   blind_key  : 32 secret bytes (host pointer) from the OS CSPRNG; the device expands slot j of proof p as
+ *                (c0 + 2^256 c1) mod r, c_h = SHA-256(key || "bppb" || (index_base + p) as u64 LE || j as u32 LE || h as
+ *                u32 LE) read little-endian (zero -> one).  index_base is the GLOBAL index of this call's first proof: a
+ *                key must never meet the same index twice.
+ * Both NULL: the literals above (for parity tests against the oracle's transcript-mode prover; such proofs leak).
+ * host buffers, as bpp_range_prove_batch */
 int bpp_range_prove_batch_fs(bpp_verifier *engine, const uint64_t *v, const uint64_t *gamma, size_t count,
-                             uint64_t *out_points, uint64_t *out_scalars, uint64_t *out_V);
+                             const uint8_t *blind_key, uint64_t index_base, uint64_t *out_points, uint64_t *out_scalars,
+                             uint64_t *out_V);
 /* device buffers, as bpp_range_prove_batch_device; d_out_challenges: count x (3 + k) scalars [y, z, e, e_1..e_k] the
  * prover drew (may be NULL) */
 int bpp_range_prove_batch_fs_device(bpp_verifier *engine, const uint64_t *d_v, const uint64_t *d_gamma, size_t count,
+                                    const uint8_t *blind_key, uint64_t index_base, const uint64_t *d_blinding,
                                     uint64_t *d_out_points, uint64_t *d_out_scalars, uint64_t *d_out_V,
                                     uint64_t *d_out_challenges, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Points of unknown origin.  bpp_verifier_run takes wire points that are elements of the prime-order group by
+ * construction (what the prover, mcl, or the decoders with their subgroup check produce), and on BLS12-381 evaluates the
+ * proof-carried points through G1's endomorphism: for a curve point OUTSIDE G1 the MulVec is then not the full-curve sum
+ * (on the order-3 point T = (0, 2) the engine forms (k1 - k2) T where the definition gives (k1 + k2 z^2) T), so a proof
+ * whose R_0 was replaced by R_0 + T is ACCEPTED by the raw call where a full-curve evaluation rejects it
+ * (tests/test_gpu_round3.py pins both outcomes).  on != 0 makes every wire point of a pass go through the membership
+ * test of the decoders (csrc/ec.hpp aff_in_prime_subgroup; two multiplications by |z| per point, about +20 % on a (64,16)
+ * pass); a point outside the group then counts as an invalid point and its proof gets verdict 1.  Off by default.  A
+ * no-op on secp256k1 (cofactor 1); the edwards25519 instantiation works in ristretto255's quotient group instead: its
+ * verdict test accepts a sum in E[4] (csrc/ristretto.hpp), i.e. points that differ by 4-torsion are THE SAME element
+ * for every ed25519 entry point, raw wire points included -- the transcript hashes their ristretto255 encoding. */
+int bpp_verifier_set_subgroup_check(bpp_verifier *v, int on);
 
 /* Per-stage timing with HIP events recorded on the caller's stream around the kernels of a pass
  * (stages: 0 wire->Montgomery, 1 verifier scalars, 2 fixed-generator MSM [dominant; its first blocks also run
@@ -283,12 +318,14 @@ int bpp_range_verify_batch(bpp_verifier *v, const uint64_t *points, const uint64
 size_t bpp_point_compressed_bytes(int curve_id);
 int bpp_points_compress(bpp_ctx *ctx, const uint64_t *points, size_t n, uint8_t *out);
 int bpp_points_decompress(bpp_ctx *ctx, const uint8_t *in, size_t n, uint64_t *out_points, uint32_t *out_ok);
-/* device buffers, asynchronous on `stream`: feeds bpp_verifier_run's d_points without touching the host */
+/* device buffers, asynchronous on `stream`: feeds bpp_verifier_run's d_points without touching the host.
+ * check_subgroup != 0: a curve point outside the prime-order subgroup is malformed too (BLS12-381 G1; what the container
+ * decoder always does) */
 int bpp_points_decompress_device(bpp_ctx *ctx, const void *d_in, size_t n, uint64_t *d_points, uint32_t *d_ok,
-                                 void *stream);
+                                 int check_subgroup, void *stream);
 /* bpp_range_verify_batch over serialized proofs: records = count x (3 + 2k + m) compressed points in the order
- * of d_points above, scalars = count x 3 (4 x u64 each).  A malformed point or a scalar >= the group order
- * rejects its proof. */
+ * of d_points above, scalars = count x 3 (4 x u64 each).  out_ok[p] = 0 Ok / 1 VerificationError / 2 FormatError: a
+ * malformed point encoding, a point outside the prime-order subgroup or a scalar >= the group order is a FormatError. */
 int bpp_range_verify_batch_compressed(bpp_verifier *v, const uint8_t *records, const uint64_t *scalars, size_t count,
                                       uint32_t *out_ok);
 

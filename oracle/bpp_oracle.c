@@ -532,6 +532,22 @@ static tr_t g_tr;             /* the running transcript of the proof being made 
 static fe_t *g_fs_rounds = NULL;   /* verifier side: e_1..e_k derived from the proof */
 static fe_t g_fs_y, g_fs_z, g_fs_e;
 EXPORT void orc_set_transcript(int on) { g_fs = on; }
+/* Blinding supplied by the caller instead of the reference's literals (include/bpp_amd.h "Blinding"; the engine's
+ * transcript-mode prover takes it from a key): (5 + 2k) canonical scalars of 4 x u64
+ * [alpha, r, s, delta, eta, d_L[0..k), d_R[0..k)]; NULL switches back to the literals.  Global, like the transcript mode. */
+static u64 *g_blind = NULL;
+static size_t g_blind_k = 0;
+EXPORT void orc_set_blinding(const u64 *values, size_t k) {
+    free(g_blind); g_blind = NULL; g_blind_k = 0;
+    if (!values) return;
+    g_blind = (u64 *)malloc(sizeof(u64) * 4 * (5 + 2 * k));
+    memcpy(g_blind, values, sizeof(u64) * 4 * (5 + 2 * k));
+    g_blind_k = k;
+}
+/* slot: 0 alpha, 1 r, 2 s, 3 delta, 4 eta, 5 + t d_L[t], 5 + k + t d_R[t] */
+static void blind_or(const field_t *fr, fe_t *out, size_t slot, int32_t literal) {
+    if (g_blind) fe_to_mont(fr, out, g_blind + 4 * slot); else fe_from_i32(fr, out, literal);
+}
 
 enum { ALPHA_SINGLE = 7, ALPHA_MULTI = 33, Y_SINGLE = 7, Z_SINGLE = 7, Y_MULTI = 12, Z_MULTI = 23,
        D_L = 4, D_R = 5, E_ROUND = 7, WIP_R = 33, WIP_S = 44, WIP_DELTA = 88, WIP_ETA = 123,
@@ -583,7 +599,7 @@ static void wip_prove(const curve_t *c, const pk_t *pk, wip_t *out, const fe_t *
         fe_t c_L, c_R, d_L, d_R, y_nhat, y_nhat_inv;
         weighted_inner_product(fr, &c_L, a1, b2, y1, n);
         weighted_inner_product(fr, &c_R, a2, b1, y2, n);
-        fe_from_i32(fr, &d_L, D_L); fe_from_i32(fr, &d_R, D_R);
+        blind_or(fr, &d_L, 5 + round, D_L); blind_or(fr, &d_R, 5 + g_blind_k + round, D_R);
         y_nhat = y1[n - 1]; fe_inv(fr, &y_nhat_inv, &y_nhat);
         /* L = MSM([y^-1 a1 | b2 | c_L | d_L], [G2 | H1 | g | h])   wip.rs:103-113 */
         for (size_t i = 0; i < n; i++) { fe_mul(fr, &sc[i], &y_nhat_inv, &a1[i]); ps[i] = G2[i]; }
@@ -618,8 +634,8 @@ static void wip_prove(const curve_t *c, const pk_t *pk, wip_t *out, const fe_t *
         fe_add(fr, &alpha, &alpha, &t);
     }
     fe_t r, s, delta, eta, rcbsca, rcs, t, u, e;
-    fe_from_i32(fr, &r, WIP_R); fe_from_i32(fr, &s, WIP_S);
-    fe_from_i32(fr, &delta, WIP_DELTA); fe_from_i32(fr, &eta, WIP_ETA);
+    blind_or(fr, &r, 1, WIP_R); blind_or(fr, &s, 2, WIP_S);
+    blind_or(fr, &delta, 3, WIP_DELTA); blind_or(fr, &eta, 4, WIP_ETA);
     fe_mul(fr, &t, &r, &yp[0]); fe_mul(fr, &t, &t, &b[0]);
     fe_mul(fr, &u, &s, &yp[0]); fe_mul(fr, &u, &u, &a[0]); fe_add(fr, &rcbsca, &t, &u);
     fe_mul(fr, &rcs, &r, &yp[0]); fe_mul(fr, &rcs, &rcs, &s);
@@ -766,7 +782,7 @@ static void range_prove(const curve_t *c, const pk_t *pk, size_t n, size_t m, co
     const size_t mn = n * m;
     fe_t alpha, y, z, two, t, u;
     fe_from_i32(fr, &two, 2);
-    fe_from_i32(fr, &alpha, m == 1 ? ALPHA_SINGLE : ALPHA_MULTI);
+    blind_or(fr, &alpha, 0, m == 1 ? ALPHA_SINGLE : ALPHA_MULTI);
     unsigned char *bits = (unsigned char *)malloc(mn);
     u64 kk[4]; fr_to_k(c, kk, &alpha);
     pt_t A, nh; pt_mul(c, &A, &pk->h, kk);

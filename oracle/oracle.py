@@ -258,6 +258,31 @@ def set_transcript(on: bool):
     lib().orc_set_transcript(1 if on else 0)
 
 
+def set_blinding(values):
+    """Blinding of the oracle's prover: None = the reference's literals, else 5 + 2k ints
+    [alpha, r, s, delta, eta, d_L[0..k), d_R[0..k)] (include/bpp_amd.h "Blinding").  Global; reset after use."""
+    if values is None:
+        lib().orc_set_blinding(None, 0)
+        return
+    k = (len(values) - 5) // 2
+    assert len(values) == 5 + 2 * k
+    w = scalars_to_wire(list(values))
+    lib().orc_set_blinding(_p(w), k)
+
+
+def blinding_from_key(key: bytes, index: int, k: int, r: int):
+    """the key expansion of csrc/prover_batch.hpp k_pb_blind, restated with hashlib: slot j of proof `index` is
+    (c0 + 2^256 c1) mod r with c_h = SHA-256(key || "bppb" || index u64 LE || j u32 LE || h u32 LE) little-endian"""
+    import hashlib
+    out = []
+    for j in range(5 + 2 * k):
+        c = [int.from_bytes(hashlib.sha256(key + b"bppb" + index.to_bytes(8, "little") + j.to_bytes(4, "little") +
+                                           h.to_bytes(4, "little")).digest(), "little") for h in (0, 1)]
+        v = (c[0] + (c[1] << 256)) % r
+        out.append(v or 1)
+    return out
+
+
 def sha256(data: bytes) -> bytes:
     out = ctypes.create_string_buffer(32)
     lib().orc_sha256(data, ctypes.c_size_t(len(data)), out)

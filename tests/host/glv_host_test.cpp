@@ -7,8 +7,10 @@
 #include "../../bulletproofsplus_amd/csrc/ec.hpp"
 using namespace bpp;
 
+// argv[1] == "secp": the signed split of secp256k1 (glv_split_signed): prints "s1 k1 s2 k2" (signs as 0 / 1)
 int main(int argc, char** argv) {
-    for (int a = 1; a < argc; a++) {
+    const bool secp = argc > 1 && strcmp(argv[1], "secp") == 0;
+    for (int a = secp ? 2 : 1; a < argc; a++) {
         const char* h = argv[a];
         if (strlen(h) != 64) return 2;
         uint32_t k[8], k1[4], k2[4];
@@ -17,6 +19,13 @@ int main(int argc, char** argv) {
             memcpy(buf, h + 8 * (7 - w), 8);
             buf[8] = 0;
             k[w] = (uint32_t)strtoul(buf, nullptr, 16);
+        }
+        if (secp) {
+            bool n1, n2;
+            glv_split_signed<Secp256k1>(k, k1, k2, n1, n2);
+            printf("%d %08x%08x%08x%08x %d %08x%08x%08x%08x\n", n1 ? 1 : 0, k1[3], k1[2], k1[1], k1[0], n2 ? 1 : 0, k2[3], k2[2], k2[1],
+                   k2[0]);
+            continue;
         }
         glv_split<Bls12381>(k, k1, k2);
         printf("%08x%08x%08x%08x %08x%08x%08x%08x\n", k1[3], k1[2], k1[1], k1[0], k2[3], k2[2], k2[1], k2[0]);

@@ -110,7 +110,8 @@ def test_device_codec_matches_oracle(cname):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cname", ["bls12_381", "secp256k1"])
 def test_verify_serialized_proofs(cname):
-    """bpp_range_verify_batch_compressed == the wire-format verdicts; a malformed point rejects its proof only."""
+    """bpp_range_verify_batch_compressed == the wire-format verdicts; a malformed point, a point outside the prime-order
+    subgroup or a non-canonical scalar makes its proof (only) a FormatError (2)."""
     need_gpu()
     import bulletproofsplus_amd as B
     a = B.Arith.init(cname)
@@ -131,12 +132,21 @@ def test_verify_serialized_proofs(cname):
     enc2 = enc.copy()
     enc2[2, 3, 0] = 0x04 if cname == "secp256k1" else 0x00
     enc2[3, 0, 0] ^= 0x01 if cname == "secp256k1" else 0x20
-    assert eng.verify_compressed(enc2, bad_sc).tolist() == [0, 1, 1, 1]
+    assert eng.verify_compressed(enc2, bad_sc).tolist() == [0, 1, 2, 1]
+    if cname == "bls12_381":
+        # a G1 point + the order-3 torsion point (0, 2): on the curve, outside the group -- the compressed path rejects it
+        # at decode time (the raw wire path would evaluate it through the endomorphism, tests/test_gpu_round3.py)
+        T = O.point_to_wire(0, (0, 2))
+        enc3 = enc.copy()
+        mixed = O.point_add(0, recs[0, 4], T)
+        assert O.on_curve(0, mixed)
+        enc3[0, 4] = B.compress_points(a, mixed[None])[0]
+        assert eng.verify_compressed(enc3, sc).tolist() == [2, 0, 0, 0]
     # a non-canonical scalar (s' + r, the same residue) is a second encoding of the same proof: rejected here,
     # while the wire-format entry point reduces it and accepts
     r = CURVES[cname]["r"]
     nc = sc.copy()
     nc[0, 1] = O.int_to_limbs(O.limbs_to_int(sc[0, 1]) + r, 4) if O.limbs_to_int(sc[0, 1]) + r < 2**256 else nc[0, 1]
     if not np.array_equal(nc, sc):
-        assert eng.verify_compressed(enc, nc).tolist() == [1, 0, 0, 0]
+        assert eng.verify_compressed(enc, nc).tolist() == [2, 0, 0, 0]
         assert eng.verify_wire(recs, nc).tolist() == [0, 0, 0, 0]

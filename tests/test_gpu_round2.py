@@ -100,11 +100,15 @@ def test_c2_bench_geometry_c17_8192_proofs():
     a = B.Arith.init("bls12_381")
     opk = O.PublicKey(O.BLS12_381, n * m)
     pk = B.PublicKey.new(a, n * m)
+    torch.cuda.empty_cache()
+    free_before, _ = torch.cuda.mem_get_info()
     try:
         bv = B.BatchVerifier(pk, n, m, window_bits=c)
     except B.BppError as e:
-        if e.code == -5:
-            pytest.skip("204 GB of free HBM needed for the c = 17 tables")
+        # the one test of the bench geometry: a box that HAS the memory (204 GB of tables + workspace) and still says
+        # NOMEM is a failure, not a skip
+        if e.code == -5 and free_before < 225 * (1 << 30):
+            pytest.skip("c = 17 tables need 204 GB of free HBM; this box has %.0f GB free" % (free_before / 2**30))
         raise
     recs, scs, vals, gams = _prove_batch(bv, count, m, seed0=5)
     k = bv.k

@@ -46,3 +46,32 @@ def test_glv_split_matches_integers():
             k1, k2 = (int(x, 16) for x in line.split())
             assert (k1, k2) == (k % z2, k // z2), hex(k)
             assert k1 < (1 << 128) and k2 < (1 << 128)
+
+
+def test_glv_split_secp256k1_signed():
+    """k == (+-k1) + (+-k2) lambda mod n with both magnitudes below 2^128 -- random scalars and the edges (0, 1, n - 1,
+    lambda, n - lambda, the middle of the range, values that make either half negative)"""
+    exe = _build("glv_host_test", "-O2")
+    n = P.SECP256K1["r"]
+    lam = 0x5363ad4cc05c30e0a5261c028812645a122e22ea20816678df02967c1b23bd72
+    assert (lam * lam + lam + 1) % n == 0
+    rng = random.Random(12)
+    ks = [0, 1, 2, n - 1, n - 2, lam, n - lam, lam + 1, lam - 1, (n - 1) // 2, (n + 1) // 2, (1 << 128) - 1, 1 << 128, (1 << 255),
+          (1 << 256) - 1 - ((1 << 256) - n) - 5]
+    ks += [rng.randrange(n) for _ in range(4000)]
+    ks += [(a + b * lam) % n for a in (1, -1, (1 << 127) - 1, -(1 << 127) + 1) for b in (1, -1, (1 << 127) - 1, -(1 << 127) + 1)]
+    ks = [k % n for k in ks]
+    seen_neg = [0, 0]
+    for off in range(0, len(ks), 500):
+        chunk = ks[off:off + 500]
+        out = subprocess.check_output([exe, "secp"] + ["%064x" % k for k in chunk]).decode().split("\n")
+        for k, line in zip(chunk, out):
+            s1, k1, s2, k2 = line.split()
+            k1, k2 = int(k1, 16), int(k2, 16)
+            v1 = -k1 if s1 == "1" else k1
+            v2 = -k2 if s2 == "1" else k2
+            assert (v1 + v2 * lam - k) % n == 0, hex(k)
+            assert k1 < (1 << 128) and k2 < (1 << 128), hex(k)
+            seen_neg[0] += s1 == "1"
+            seen_neg[1] += s2 == "1"
+    assert seen_neg[0] > 100 and seen_neg[1] > 100

@@ -15,7 +15,7 @@ d_ok = torch.zeros(n, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 L = _lib.lib()
 def run():
-    rc = L.bpp_points_decompress_device(a.handle, d_in.data_ptr(), n, d_out.data_ptr(), d_ok.data_ptr(), st)
+    rc = L.bpp_points_decompress_device(a.handle, d_in.data_ptr(), n, d_out.data_ptr(), d_ok.data_ptr(), 0, st)
     assert rc == 0
 run(); torch.cuda.synchronize()
 t0 = time.perf_counter()
