@@ -193,18 +193,12 @@ extern "C" int bpp_commit(bpp_ctx* ctx, const uint64_t* gh, uint64_t v, const ui
     return dispatch(ctx->curve, [&](auto cv) -> int { return MsmImpl<decltype(cv)>::commit(gh, v, gamma, out); });
 }
 
-extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
-                                size_t m, const uint64_t* proof_points, size_t k, const uint64_t* proof_scalars,
-                                const uint64_t* V) {
-    if (!ctx || !gh || !G || !H || !proof_points || !proof_scalars || !V) return fail(BPP_E_ARG, "null argument");
-    HIPCHK(hipSetDevice(ctx->device));
-    auto naive = [&]() -> int {
-        return dispatch(ctx->curve, [&](auto cv) -> int {
-            return MsmImpl<decltype(cv)>::range_verify_single(gh, G, H, n, m, proof_points, k, proof_scalars, V);
-        });
-    };
+// The cached engine of a public key, or null when the call has to take the table-free path: first sight of the key (it
+// is remembered), a shape the engine does not take, the cache switched off, or no memory for the tables.
+static VerifyCacheEntry* engine_for_key(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
+                                        size_t m) {
     const size_t mn = n * m;
-    if (n == 0 || m == 0 || n > VS_MAXN || m > VS_MAXM || (mn & (mn - 1)) || ctx->verify_cache_off) return naive();
+    if (n == 0 || m == 0 || n > VS_MAXN || m > VS_MAXM || (mn & (mn - 1)) || ctx->verify_cache_off) return nullptr;
     const size_t pw = (size_t)bpp_point_words(ctx->curve);
     if (!ctx->verify_cache) ctx->verify_cache = new VerifyCache();
     VerifyCache& vc = *static_cast<VerifyCache*>(ctx->verify_cache);
@@ -216,7 +210,7 @@ extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t
             std::memcmp(x->key.data() + 2 * pw, G, mn * pw * 8) == 0 &&
             std::memcmp(x->key.data() + (2 + mn) * pw, H, mn * pw * 8) == 0)
             hit = x;
-    if (!hit) {   // first sight of this key: remember it, answer by the naive MulVec
+    if (!hit) {   // first sight of this key: remember it
         if (vc.e.size() >= VCACHE_MAX) {
             size_t old = 0;
             for (size_t i = 1; i < vc.e.size(); i++)
@@ -235,21 +229,36 @@ extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t
         std::memcpy(x->key.data() + (2 + mn) * pw, H, mn * pw * 8);
         x->stamp = ++vc.clock;
         vc.e.push_back(x);
-        return naive();
+        return nullptr;
     }
     hit->stamp = ++vc.clock;
-    if (!hit->v) {   // the key came back: build its tables (an invalid generator or no memory: stay with the naive path)
+    if (!hit->v) {   // the key came back: build its tables (an invalid generator or no memory: stay with the table-free path)
         bpp_verifier* v = nullptr;
-        int rc = bpp_verifier_create(ctx, gh, G, H, n, m, VCACHE_WINDOW, &v);
-        if (rc) return naive();
+        if (bpp_verifier_create(ctx, gh, G, H, n, m, VCACHE_WINDOW, &v)) return nullptr;
         const size_t wsb = bpp_verifier_workspace_bytes(v, 1);
         if (hit->pts.alloc(v->s.NV * pw * 8) != hipSuccess || hit->sc.alloc(96) != hipSuccess ||
             hit->ok.alloc(4) != hipSuccess || hit->ws.alloc(wsb) != hipSuccess) {
             delete v;
-            return naive();
+            return nullptr;
         }
         hit->v = v;
     }
+    return hit;
+}
+
+extern "C" int bpp_range_verify(bpp_ctx* ctx, const uint64_t* gh, const uint64_t* G, const uint64_t* H, size_t n,
+                                size_t m, const uint64_t* proof_points, size_t k, const uint64_t* proof_scalars,
+                                const uint64_t* V) {
+    if (!ctx || !gh || !G || !H || !proof_points || !proof_scalars || !V) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto naive = [&]() -> int {
+        return dispatch(ctx->curve, [&](auto cv) -> int {
+            return MsmImpl<decltype(cv)>::range_verify_single(gh, G, H, n, m, proof_points, k, proof_scalars, V);
+        });
+    };
+    VerifyCacheEntry* hit = engine_for_key(ctx, gh, G, H, n, m);
+    if (!hit) return naive();
+    const size_t pw = (size_t)bpp_point_words(ctx->curve);
     bpp_verifier* v = hit->v;
     if (k != v->s.k) return BPP_VERIFICATION_ERROR;   // wip.rs:335-337
     // record [A, wip.A, wip.B, L.., R.., V..]
@@ -280,6 +289,22 @@ extern "C" int bpp_range_prove(bpp_ctx* ctx, const uint64_t* gh, const uint64_t*
     if (!ctx || !gh || !G || !H || !v || !gamma || !V || !out_points || !out_scalars)
         return fail(BPP_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ctx->device));
+    // a key that has been seen before proves through its cached engine: the batched prover at count = 1 (every L, R, A, B
+    // one MulVec over the window tables, bit-identical output) instead of folding the generator vectors round by round
+    if (VerifyCacheEntry* hit = engine_for_key(ctx, gh, G, H, n, m)) {
+        // the batched prover forms the commitments from (v, gamma) itself; the reference's prove reads them from the
+        // prover object (range/mod.rs:330-343) -- if the caller's V are not those, only the fold-based path reproduces it
+        const size_t pw = (size_t)bpp_point_words(ctx->curve);
+        std::vector<uint64_t> myV(m * pw), pts((3 + 2 * hit->v->s.k) * pw), sc(12);
+        int rc = dispatch(ctx->curve, [&](auto cv) -> int {
+            return VerifyImpl<decltype(cv)>::prove_batch(hit->v, v, gamma, 1, pts.data(), sc.data(), myV.data(), false);
+        });
+        if (rc == BPP_OK && std::memcmp(myV.data(), V, m * pw * 8) == 0) {
+            std::memcpy(out_points, pts.data(), pts.size() * 8);
+            std::memcpy(out_scalars, sc.data(), 96);
+            return BPP_OK;
+        }
+    }
     return dispatch(ctx->curve, [&](auto cv) -> int {
         std::string err;
         int rc = ProveImpl<decltype(cv)>::range_prove(gh, G, H, n, m, v, gamma, V, out_points, out_scalars, err);

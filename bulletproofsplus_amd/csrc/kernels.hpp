@@ -166,6 +166,64 @@ __device__ __forceinline__ Jac<C> block_reduce_jac(Jac<C> acc, uint32_t* lds) {
     return acc;
 }
 
+// wave-wide exchange of a whole struct of 32-bit words (ds_bpermute per word; no LDS memory is touched)
+template <class T>
+__device__ __forceinline__ T wave_shfl(const T& v, int src_lane) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    struct Words {
+        uint32_t w[sizeof(T) / 4];
+    };
+    Words a = __builtin_bit_cast(Words, v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); i++) a.w[i] = (uint32_t)__shfl((int)a.w[i], src_lane, 64);
+    return __builtin_bit_cast(T, a);
+}
+
+// sum over groups of `span` lanes (a power of two <= 64) of a wave (butterfly: every lane ends with its group's total)
+template <class C>
+__device__ __forceinline__ Jac<C> wave_sum_jac(Jac<C> x, int span = 64) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int d = span >> 1; d >= 1; d >>= 1) {
+        const Jac<C> o = wave_shfl(x, lane ^ d);
+        x = jac_add(x, o);
+    }
+    return x;
+}
+
+// A doubling shared by THREE lanes (lanes 3g, 3g+1, 3g+2 of a wave hold the same jacobian point; every lane of the
+// wave calls this; all three return 2 p).  dbl-2009-l is 2M + 5S in a row for one lane -- ~10 us on the 13-limb field,
+// and the Horner tails (the verifier's proof-point MulVec, the bucket MulVec) are chains of 110..130 of them that
+// nothing else can hide.  Its seven products have a dependency depth of three, so three lanes finish in three
+// product-times: level 1  X^2 | Y^2 | Y Z ;  level 2  (3 X^2)^2 | (Y^2)^2 | (X + Y^2)^2 ;  level 3  E (D - X3), the
+// same in all three.  Operands travel by ds_bpermute (78 words per doubling).  Z = 0 stays Z = 0 (infinity), whatever
+// X and Y turn into.  Short-Weierstrass a = 0 curves only.
+template <class C>
+__device__ __forceinline__ Jac<C> jac_dbl_tri(const Jac<C>& p) {
+    using F = Fe<typename C::Fp>;
+    static_assert(C::ID != 2, "short-Weierstrass curves");
+    const int lane = threadIdx.x & 63;
+    const int role = lane % 3, g0 = lane - role;
+    auto pick = [](bool c, const F& a, const F& b) {
+        F r;
+#pragma unroll
+        for (int i = 0; i < C::Fp::NL; i++) r.l[i] = c ? a.l[i] : b.l[i];
+        return r;
+    };
+    const F m1 = fe_mul(pick(role == 0, p.X, p.Y), pick(role == 0, p.X, pick(role == 1, p.Y, p.Z)));   // A | B | Y Z
+    const F B = wave_shfl(m1, (g0 + 1) & 63);
+    const F m2 = fe_sqr(pick(role == 0, fe_add(fe_dbl(m1), m1), pick(role == 1, m1, fe_add(p.X, B))));   // F | C | t
+    const F A = wave_shfl(m1, g0), Fq = wave_shfl(m2, g0), Cc = wave_shfl(m2, (g0 + 1) & 63);
+    const F t = wave_shfl(m2, (g0 + 2) & 63), YZ = wave_shfl(m1, (g0 + 2) & 63);
+    const F D = fe_dbl(fe_sub(fe_sub(t, A), Cc));
+    const F E = fe_add(fe_dbl(A), A);
+    Jac<C> r;
+    r.X = fe_sub(Fq, fe_dbl(D));
+    r.Y = fe_sub(fe_mul(E, fe_sub(D, r.X)), fe_dbl(fe_dbl(fe_dbl(Cc))));
+    r.Z = fe_dbl(YZ);
+    return r;
+}
+
 // ---- wire <-> device images --------------------------------------------------------------------------
 
 // wire points -> affm.  per_group > 0: bad[i / per_group] is set when point i is invalid (coordinate
@@ -817,6 +875,34 @@ __device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsu
     if (j == 0) jac_stg<C>(out + b * JW, acc);
 }
 
+// The wave-per-proof form for the curves with 33 windows (GLV), as a BLOCK of two waves: three lanes per window share
+// every doubling (jac_dbl_tri above) -- window j doubles its sum 4 j times, all windows at once, so the critical path is
+// the top window's 128 doublings at three product-times each instead of seven -- then the windows' lanes are compacted,
+// a butterfly adds them and the second wave's sum joins through LDS.  Every lane of the 128-thread block calls it.
+template <class C>
+__device__ __forceinline__ void var_horner_wave2(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
+                                                 uint32_t* lds, uint32_t groups) {
+    constexpr uint32_t NW = var_windows<C>(), PER = 21;   // windows per wave (63 lanes)
+    static_assert(NW <= 2 * PER, "two waves hold the windows");
+    constexpr int JW = jac_words<C>();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t q = lane / 3, j = wave * PER + q;
+    const bool has = q < PER && j < NW;
+    Jac<C> R = has ? var_wsum_ld<C, true>(wsum, b, j, groups) : jac_inf<C>();
+    const uint32_t times = has ? 4 * j : 0u;
+    const uint32_t maxt = 4 * (wave == 0 ? PER - 1 : NW - 1);   // wave-uniform
+    for (uint32_t t = 0; t < maxt; t++) {
+        const Jac<C> d = jac_dbl_tri<C>(R);
+        if (t < times) R = d;
+    }
+    R = wave_shfl(R, (int)((3 * lane) & 63u));
+    if (lane >= PER || wave * PER + lane >= NW) R = jac_inf<C>();
+    R = wave_sum_jac<C>(R, 32);
+    if (wave == 1 && lane == 0) jac_store(R, lds);
+    __syncthreads();
+    if (wave == 0 && lane == 0) jac_stg<C>(out + b * JW, jac_add(R, jac_load<C>(lds)));
+}
+
 // Between the two: EIGHT lanes per proof (eight proofs per wave), for batches that are too large for a wave per proof
 // but whose fixed-generator work is over before a one-lane chain would be (4 096 proofs of (64,1): the chain of 128
 // doublings + 33 additions was 2.2 of the pass's 3.7 ms).  Lane g runs Horner over its own eighth of the windows, then
@@ -946,7 +1032,11 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
                              // two tree waves in one block slowed each other down (5.8 ms for 2 proofs against 4.3 ms
                              // for one); a block per proof spreads the chains over the CUs
             const size_t b = blockIdx.x;
-            if (b < horner_count && threadIdx.x < 64) var_horner_wave<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
+            if constexpr (var_glv<C>()) {   // 33 windows: both waves, three lanes per window (var_horner_wave2)
+                if (b < horner_count) var_horner_wave2<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
+            } else {
+                if (b < horner_count && threadIdx.x < 64) var_horner_wave<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
+            }
         } else {             // one lane per proof
             const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
             if (lane < horner_count) var_horner_lane<C>(wsum, var_out, lane);

@@ -162,31 +162,6 @@ inline int pip_pick_c(size_t n) {
 constexpr uint32_t PIP_EMPTY = 0xffffffffu;
 constexpr uint32_t PIP_FOLD_MAX = 32;   // a bucket spread over more chunks than this is folded by a whole wave
 
-// wave-wide exchange of a whole struct of 32-bit words (ds_bpermute per word; no LDS memory is touched)
-template <class T>
-__device__ __forceinline__ T wave_shfl(const T& v, int src_lane) {
-    static_assert(sizeof(T) % 4 == 0, "whole words");
-    struct Words {
-        uint32_t w[sizeof(T) / 4];
-    };
-    Words a = __builtin_bit_cast(Words, v);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); i++) a.w[i] = (uint32_t)__shfl((int)a.w[i], src_lane, 64);
-    return __builtin_bit_cast(T, a);
-}
-
-// sum over groups of `span` lanes (a power of two <= 64) of a wave (butterfly: every lane ends with its group's total)
-template <class C>
-__device__ __forceinline__ Jac<C> wave_sum_jac(Jac<C> x, int span = 64) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int d = span >> 1; d >= 1; d >>= 1) {
-        const Jac<C> o = wave_shfl(x, lane ^ d);
-        x = jac_add(x, o);
-    }
-    return x;
-}
-
 // inclusive SUFFIX sums over the lanes of a wave: lane l ends with x_l + x_{l+1} + ... + x_63
 template <class C>
 __device__ __forceinline__ Jac<C> wave_suffix_jac(Jac<C> x) {
@@ -587,6 +562,34 @@ __global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __
     constexpr int JW = jac_words<C>();
     if (blockIdx.x != 0) return;
     const uint32_t lane = threadIdx.x & 63u;
+    if constexpr (C::ID != 2) {
+        if (3 * s.W <= 64) {
+            // few windows (the usual case: W = 8..20): THREE lanes per window share every doubling (jac_dbl_tri,
+            // kernels.hpp: three levels of one field product each instead of seven products in a row), then the windows'
+            // lanes are compacted and summed by the butterfly
+            const uint32_t j = lane / 3;
+            Jac<C> R = j < s.W ? jac_ldg<C>(window_sums + (size_t)j * JW) : jac_inf<C>();
+            const uint32_t times = j < s.W ? s.off(j) : 0u, maxt = s.off(s.W - 1);
+            for (uint32_t t = 0; t < maxt; t++) {
+                const Jac<C> d = jac_dbl_tri<C>(R);
+                if (t < times) R = d;
+            }
+            R = wave_shfl(R, (int)((3 * lane) & 63u));
+            if (lane >= s.W) R = jac_inf<C>();
+            uint32_t span = 1;
+            while (span < s.W) span <<= 1;
+            R = wave_sum_jac<C>(R, (int)span);
+            if (lane != 0) return;
+            if (out_jac) jac_stg<C>(out_jac, R);
+            if (out_wire) {
+                uint32_t w[2 * N + 2];
+                aff_to_wire(jac_to_aff(R), w);
+#pragma unroll
+                for (int t = 0; t < 2 * N + 2; t++) out_wire[t] = w[t];
+            }
+            return;
+        }
+    }
     Jac<C> acc = jac_inf<C>();
     uint32_t at = 0;   // acc is in units of 2^at
     for (uint32_t hi = ((s.W - 1 - lane) / 64) * 64 + lane; lane < s.W; hi -= 64) {   // windows lane + 64 i, highest first
