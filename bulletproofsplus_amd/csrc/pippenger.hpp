@@ -24,12 +24,13 @@
 // SEGMENT it touches; a bucket's sum is the sum of its segments (k_pip_fold).
 //
 // Pipeline (one stream, no host round trips):
-//   k_pip_points   wire points -> Montgomery affine (+ on-curve check) and, with GLV, the endomorphism image
-//   k_pip_digits   per point: reduce mod r, split, W digits per item -> key (bucket, sign); bucket histogram with
-//                  returning atomics, the returned value is the item's slot inside its bucket
-//   k_pip_scan     per window (one block, LDS scans): offsets = prefix sums of the histogram; per bucket the number of
-//                  chunks it touches and the prefix sums of that (segment bases); per chunk its first bucket
-//   k_pip_scatter  per (window, item): sorted[offset[bucket] + slot] = item | sign
+//   k_pip_points   wire points -> Montgomery affine (+ on-curve check) and, with GLV, the endomorphism image; the
+//                  point's scalar reduced mod r and split, once
+//   k_pip_count / k_pip_cscan / k_pip_place / k_pip_binsort   per window a counting sort of the items by bucket, in
+//                  two levels (coarse bins of 32..256 buckets, then the buckets of a bin) with every per-entry atomic in LDS;
+//                  out: sorted[j] = items in bucket order, counts / offsets per bucket
+//   k_pip_segments per window (one block, LDS scan): per bucket the number of chunks it touches and the prefix sums of
+//                  that (segment bases); per chunk its first bucket
 //   k_pip_chunks   per (window, chunk): XYZZ running sums over the chunk's entries, gathered through the LDS-DMA ring
 //                  of k_fixed_msm (kernels.hpp), flushed as a jacobian at every bucket boundary and at the chunk's end
 //   k_pip_fold     per bucket: sum of its segments (buckets spread over more than PIP_FOLD_MAX chunks: one wave each,
@@ -66,6 +67,7 @@ struct PipShape {
     uint32_t S, TS;            // buckets per lane / per tile (64 S) in k_pip_tiles
     uint32_t tw, tn, ntiles;   // tiles of a wide / narrow signed window, all tiles
     uint32_t L, cpw, capseg;   // entries per chunk, chunks per window, segment slots per window
+    uint32_t fb;               // log2 of the buckets per coarse bin of the sort (5..8)
     uint32_t bias[10];         // sum over the signed windows of half their range at their offset
 
     __host__ __device__ uint32_t width(uint32_t j) const { return q + (j < nwide ? 1u : 0u); }
@@ -130,6 +132,10 @@ inline int pip_shape(size_t n, int c, bool glv, const uint32_t* max_words, int b
     uint32_t L = 64;
     while (L > 8 && entries / L < ((size_t)1 << 18)) L >>= 1;
     s.L = L;
+    // coarse bins of the sort: about 1024 of them (one block of k_pip_binsort each), 32..256 buckets wide
+    uint32_t fb = 8;
+    while (fb > 5 && (s.nbuckets >> fb) < 1024) fb--;
+    s.fb = fb;
     s.cpw = (s.items + L - 1) / L;
     s.capseg = s.cpw + s.nbmax;
     return BPP_OK;
@@ -177,12 +183,45 @@ __device__ __forceinline__ Jac<C> wave_suffix_jac(Jac<C> x) {
 // ---- points -----------------------------------------------------------------------------------------------
 // wire -> affm; items n..2n-1 (GLV): the image under the endomorphism, (beta x, -y) / (beta x, y).  bad[0] |= 1 for an invalid point
 // (replaced by infinity).
+// ... and the point's scalar, reduced mod r and split ONCE (the secp256k1 split is two 256 x 256-bit products and three
+// products mod n: recomputing it per window in the sort cost more than the sort): split[i] = k1 (4 words) | k2 (4 words) |
+// sign bits (bit 0: k1 negative, bit 1: k2 negative) | 3 spare words; without an endomorphism: the reduced scalar (8 words).
+constexpr uint32_t PIP_SPLIT_WORDS = 12;
 template <class C>
 __global__ void __launch_bounds__(128) k_pip_points(PipShape s, const uint32_t* __restrict__ wire,
-                                                    uint32_t* __restrict__ affm, uint32_t* __restrict__ bad) {
+                                                    const uint32_t* __restrict__ scalars, uint32_t* __restrict__ affm,
+                                                    uint32_t* __restrict__ split, uint32_t* __restrict__ bad) {
     constexpr int N = C::Fp::N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
+    {
+        uint32_t k[8];
+        ld_words<8>(scalars + i * 8, k);
+        for (int it = 0; it < 16 && !words_lt_mod<typename C::Fr>(k); it++) {   // PrimeFieldElem values are < r
+            uint32_t borrow = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint64_t d = (uint64_t)k[t] - C::Fr::MODW[t] - borrow;
+                k[t] = (uint32_t)d;
+                borrow = (uint32_t)(d >> 63);
+            }
+        }
+        uint32_t o[PIP_SPLIT_WORDS];
+#pragma unroll
+        for (int t = 0; t < (int)PIP_SPLIT_WORDS; t++) o[t] = t < 8 ? k[t] : 0u;
+        if constexpr (pip_glv<C>()) {
+            uint32_t k1[4], k2[4];
+            bool n1, n2;
+            glv_split_signed<C>(k, k1, k2, n1, n2);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                o[t] = k1[t];
+                o[4 + t] = k2[t];
+            }
+            o[8] = (n1 ? 1u : 0u) | (n2 ? 2u : 0u);
+        }
+        st_words<PIP_SPLIT_WORDS>(split + i * PIP_SPLIT_WORDS, o);
+    }
     uint32_t w[2 * N + 2];
 #pragma unroll
     for (int t = 0; t < 2 * N + 2; t++) w[t] = wire[i * (2 * N + 2) + t];
@@ -205,135 +244,251 @@ __global__ void __launch_bounds__(128) k_pip_points(PipShape s, const uint32_t* 
     }
 }
 
-// ---- digits, histogram ------------------------------------------------------------------------------------
-// keys / slots: [W][items]; counts: [nbuckets] (zeroed by the caller)
+// ---- digits and the sort by bucket -----------------------------------------------------------------------------
+// A counting sort per window in two levels, with every per-entry atomic in LDS.  (Global atomics execute at the memory
+// side on this chip: one returning atomic per (item, window) -- 67 M of them at N = 2^22 -- ran at the chip-wide
+// atomic rate and cost a third of the whole MulVec.)
+//   level 1, coarse bins of 2^fb consecutive buckets (fb = 5..8, chosen so that there are about a thousand bins):
+//     k_pip_count   per (window, block of PIP_CHUNK points): digit -> coarse bin, LDS histogram, ONE global add per
+//                   (block, coarse bin)
+//     k_pip_cscan   offsets of the coarse bins inside their window's row; wtotal
+//     k_pip_place   the same walk again: LDS rank inside the block, ONE global add per (block, coarse bin) reserves the
+//                   block's run inside the bin, records (item | sign, bucket mod 512) go to their bin
+//   level 2, k_pip_binsort: one block per (window, coarse bin): LDS histogram over the bin's <= 256 buckets, LDS scan,
+//                   counts[] and offsets[] of those buckets, then the records are placed in bucket order in `sorted`
+//   k_pip_segments  per window (one block, LDS scan): per bucket the number of chunks it touches and the prefix sums of
+//                   that (segment bases); per chunk its first bucket
+constexpr uint32_t PIP_FINE_MAX = 256;      // buckets per coarse bin: 2^fb, fb in [5, 8] (PipShape::fb)
+constexpr uint32_t PIP_CHUNK = 2048;        // points per block of k_pip_count / k_pip_place (256 threads x 8)
+constexpr uint32_t PIP_IPT = PIP_CHUNK / 256;
+constexpr uint32_t PIP_MAXCOARSE = 2052;    // coarse bins of the largest window: (2^16 + 1) / 32 + 1 = 2049
+
+__host__ __device__ inline uint32_t pip_ncoarse(const PipShape& s, uint32_t j) { return (s.nb(j) + (1u << s.fb) - 1) >> s.fb; }
+// coarse bins are numbered window by window; cbase(j) = bins of the windows below j (W + 1 entries fit a kernel argument
+// badly for W up to 128, so it is recomputed: windows come in at most three sizes)
+__host__ __device__ inline uint32_t pip_cbase(const PipShape& s, uint32_t j) {
+    const uint32_t fine = 1u << s.fb;
+    const uint32_t cw = ((1u << s.q) + fine - 1) >> s.fb, cn = ((1u << (s.q - 1)) + fine - 1) >> s.fb;
+    return j < s.nwide ? j * cw : s.nwide * cw + (j - s.nwide) * cn;
+}
+__host__ __device__ inline uint32_t pip_ncoarse_total(const PipShape& s) { return pip_cbase(s, s.W - 1) + pip_ncoarse(s, s.W - 1); }
+
+// the sub-scalars of point i as k_pip_points left them: w[h] = value + bias (10 words), neg[h]
 template <class C>
-__global__ void __launch_bounds__(256) k_pip_digits(PipShape s, const uint32_t* __restrict__ scalars,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ slots,
-                                                    uint32_t* __restrict__ counts) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n) return;
-    uint32_t k[8];
-    ld_words<8>(scalars + (size_t)i * 8, k);
-    for (int it = 0; it < 16 && !words_lt_mod<typename C::Fr>(k); it++) {   // PrimeFieldElem values are < r
-        uint32_t borrow = 0;
+__device__ __forceinline__ void pip_subscalars(const PipShape& s, const uint32_t* __restrict__ split, uint32_t i,
+                                               uint32_t w[2][10], bool neg[2]) {
+    uint32_t k[PIP_SPLIT_WORDS];
+    ld_words<PIP_SPLIT_WORDS>(split + (size_t)i * PIP_SPLIT_WORDS, k);
+    neg[0] = pip_glv<C>() && (k[8] & 1u);
+    neg[1] = pip_glv<C>() && (k[8] & 2u);
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const uint64_t d = (uint64_t)k[t] - C::Fr::MODW[t] - borrow;
-            k[t] = (uint32_t)d;
-            borrow = (uint32_t)(d >> 63);
-        }
-    }
-    uint32_t sub[2][8];
-    bool nh[2] = {false, false};   // a negative half: every digit changes sign
-    if constexpr (pip_glv<C>()) {
-        uint32_t k1[4], k2[4];
-        glv_split_signed<C>(k, k1, k2, nh[0], nh[1]);
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            sub[0][t] = t < 4 ? k1[t] : 0u;
-            sub[1][t] = t < 4 ? k2[t] : 0u;
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 8; t++) sub[0][t] = k[t];
-    }
-    const int halves = pip_glv<C>() ? 2 : 1;
-    for (int h = 0; h < halves; h++) {
-        const uint32_t e = i + (uint32_t)h * s.n;
-        uint32_t w[10];
+    for (int h = 0; h < 2; h++) {
         uint32_t carry = 0;
 #pragma unroll
         for (int t = 0; t < 10; t++) {
-            const uint64_t x = (uint64_t)(t < 8 ? sub[h][t] : 0u) + s.bias[t] + carry;
-            w[t] = (uint32_t)x;
+            uint32_t v;
+            if constexpr (pip_glv<C>())
+                v = t < 4 ? k[4 * h + t] : 0u;
+            else
+                v = (h == 0 && t < 8) ? k[t] : 0u;
+            const uint64_t x = (uint64_t)v + s.bias[t] + carry;
+            w[h][t] = (uint32_t)x;
             carry = (uint32_t)(x >> 32);
-        }
-        uint32_t bb = 0;
-        for (uint32_t j = 0; j < s.W; j++) {
-            const uint32_t wd = s.width(j);
-            const int32_t dg = j + 1 < s.W ? (int32_t)(w[0] & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1)) : (int32_t)w[0];
-#pragma unroll
-            for (int t = 0; t < 9; t++) w[t] = (w[t] >> wd) | (w[t + 1] << (32 - wd));
-            w[9] >>= wd;
-            uint32_t key = PIP_EMPTY, slot = 0;
-            if (dg != 0) {
-                const uint32_t b = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
-                slot = atomicAdd(&counts[bb + b], 1u);
-                key = (b << 1) | ((dg < 0) != nh[h] ? 1u : 0u);
-            }
-            keys[(size_t)j * s.items + e] = key;
-            slots[(size_t)j * s.items + e] = slot;
-            bb += 1u << (wd - 1);   // == bbase(j + 1) for every signed window
         }
     }
 }
+// digit of window j of (value + bias): signed below the top window, unsigned in it
+__device__ __forceinline__ int32_t pip_digit(const PipShape& s, const uint32_t w[10], uint32_t j) {
+    const uint32_t o = s.off(j), wi = o >> 5, sh = o & 31u;
+    uint32_t v = w[wi] >> sh;
+    if (sh && wi + 1 < 10) v |= w[wi + 1] << (32 - sh);
+    if (j + 1 == s.W) return (int32_t)v;   // everything that is left of the value (< 2^18)
+    const uint32_t wd = s.width(j);
+    return (int32_t)(v & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
+}
 
-// One block per window, two LDS scans:
-//   offsets[b]  = exclusive prefix sum of counts over the window's buckets; wtotal[j] = the window's entries
+// grid (blocks of PIP_CHUNK points, W).  ccount: [coarse bins of all windows], zeroed by the caller.
+template <class C>
+__global__ void __launch_bounds__(256) k_pip_count(PipShape s, const uint32_t* __restrict__ split,
+                                                   uint32_t* __restrict__ ccount) {
+    __shared__ uint32_t hist[PIP_MAXCOARSE];
+    const uint32_t j = blockIdx.y, t = threadIdx.x;
+    const uint32_t nc = pip_ncoarse(s, j);
+    for (uint32_t c = t; c < nc; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    constexpr int halves = pip_glv<C>() ? 2 : 1;
+    for (uint32_t q = 0; q < PIP_IPT; q++) {
+        const uint32_t i = blockIdx.x * PIP_CHUNK + q * 256 + t;
+        if (i >= s.n) break;
+        uint32_t w[2][10];
+        bool neg[2];
+        pip_subscalars<C>(s, split, i, w, neg);
+#pragma unroll
+        for (int h = 0; h < halves; h++) {
+            const int32_t dg = pip_digit(s, w[h], j);
+            if (dg != 0) atomicAdd(&hist[((dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1) >> s.fb], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* cj = ccount + pip_cbase(s, j);
+    for (uint32_t c = t; c < nc; c += blockDim.x)
+        if (hist[c]) atomicAdd(&cj[c], hist[c]);
+}
+
+// one block: cstart[bin] = exclusive prefix of ccount inside the bin's window; wtotal[j]; ccursor zeroed
+static __global__ void __launch_bounds__(256) k_pip_cscan(PipShape s, const uint32_t* __restrict__ ccount,
+                                                          uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccursor,
+                                                          uint32_t* __restrict__ wtotal) {
+    for (uint32_t j = threadIdx.x; j < s.W; j += blockDim.x) {
+        const uint32_t cb = pip_cbase(s, j), nc = pip_ncoarse(s, j);
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < nc; c++) {
+            cstart[cb + c] = run;
+            ccursor[cb + c] = 0;
+            run += ccount[cb + c];
+        }
+        wtotal[j] = run;
+    }
+}
+
+// the same walk as k_pip_count: rec_item / rec_low: [W][items], grouped by coarse bin
+template <class C>
+__global__ void __launch_bounds__(256) k_pip_place(PipShape s, const uint32_t* __restrict__ split,
+                                                   const uint32_t* __restrict__ cstart, uint32_t* __restrict__ ccursor,
+                                                   uint32_t* __restrict__ rec_item, uint16_t* __restrict__ rec_low) {
+    __shared__ uint32_t hist[PIP_MAXCOARSE];
+    const uint32_t j = blockIdx.y, t = threadIdx.x;
+    const uint32_t nc = pip_ncoarse(s, j), cb = pip_cbase(s, j);
+    for (uint32_t c = t; c < nc; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    constexpr int halves = pip_glv<C>() ? 2 : 1;
+    // per entry of this thread: (coarse bin, rank inside the block's share of it) ; item | sign ; bucket mod 512
+    uint32_t where[PIP_IPT * halves], what[PIP_IPT * halves], lowb[PIP_IPT * halves];
+#pragma unroll
+    for (uint32_t q = 0; q < PIP_IPT; q++) {
+        const uint32_t i = blockIdx.x * PIP_CHUNK + q * 256 + t;
+        uint32_t w[2][10];
+        bool neg[2] = {false, false};
+        if (i < s.n) pip_subscalars<C>(s, split, i, w, neg);
+#pragma unroll
+        for (int h = 0; h < halves; h++) {
+            where[q * halves + h] = 0xffffffffu;
+            what[q * halves + h] = 0;
+            lowb[q * halves + h] = 0;
+            if (i < s.n) {
+                const int32_t dg = pip_digit(s, w[h], j);
+                if (dg != 0) {
+                    const uint32_t b = (dg < 0 ? (uint32_t)(-dg) : (uint32_t)dg) - 1;
+                    const uint32_t c = b >> s.fb;
+                    const uint32_t rank = atomicAdd(&hist[c], 1u);      // < 2 PIP_CHUNK = 2^12
+                    where[q * halves + h] = (c << 16) | rank;
+                    what[q * halves + h] = ((i + (uint32_t)h * s.n) << 1) | (((dg < 0) != neg[h]) ? 1u : 0u);
+                    lowb[q * halves + h] = b & ((1u << s.fb) - 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t c = t; c < nc; c += blockDim.x) hist[c] = hist[c] ? atomicAdd(&ccursor[cb + c], hist[c]) : 0u;   // the block's base in bin c
+    __syncthreads();
+    uint32_t* ri = rec_item + (size_t)j * s.items;
+    uint16_t* rl = rec_low + (size_t)j * s.items;
+#pragma unroll
+    for (uint32_t q = 0; q < PIP_IPT * halves; q++) {
+        const uint32_t wh = where[q];
+        if (wh == 0xffffffffu) continue;
+        const uint32_t c = wh >> 16, rank = wh & 0xffffu;
+        const uint32_t pos = cstart[cb + c] + hist[c] + rank;
+        ri[pos] = what[q];
+        rl[pos] = (uint16_t)lowb[q];
+    }
+}
+
+// one block per (window, coarse bin): the bin's records -> bucket order.  counts / offsets: flat per bucket.
+template <class C>
+__global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const uint32_t* __restrict__ ccount,
+                                                          const uint32_t* __restrict__ cstart,
+                                                          const uint32_t* __restrict__ rec_item,
+                                                          const uint16_t* __restrict__ rec_low, uint32_t* __restrict__ counts,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[PIP_FINE_MAX], pre[PIP_FINE_MAX];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    // window of the bin
+    const uint32_t fine = 1u << s.fb;
+    const uint32_t cw = ((1u << s.q) + fine - 1) >> s.fb, cn = ((1u << (s.q - 1)) + fine - 1) >> s.fb;
+    uint32_t j;
+    if (bin < s.nwide * cw) {
+        j = bin / cw;
+    } else {
+        const uint32_t r = (bin - s.nwide * cw) / cn;
+        j = s.nwide + (r < s.W - 1 - s.nwide ? r : s.W - 1 - s.nwide);
+    }
+    const uint32_t c = bin - pip_cbase(s, j);
+    const uint32_t nb = s.nb(j), b0 = c << s.fb;
+    const uint32_t nfine = min(fine, nb - b0);
+    const uint32_t lo = cstart[bin], n = ccount[bin];
+    const uint32_t* ri = rec_item + (size_t)j * s.items + lo;
+    const uint16_t* rl = rec_low + (size_t)j * s.items + lo;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t r = t; r < n; r += blockDim.x) atomicAdd(&cnt[rl[r]], 1u);
+    __syncthreads();
+    // exclusive scan of cnt (Hillis-Steele)
+    const uint32_t mine = cnt[t];
+    pre[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < PIP_FINE_MAX; d <<= 1) {
+        const uint32_t v = t >= d ? pre[t - d] : 0;
+        __syncthreads();
+        pre[t] += v;
+        __syncthreads();
+    }
+    const uint32_t ex = pre[t] - mine;
+    if (t < nfine) {
+        counts[s.bbase(j) + b0 + t] = mine;
+        offsets[s.bbase(j) + b0 + t] = lo + ex;
+    }
+    __syncthreads();
+    cnt[t] = ex;   // cursors
+    __syncthreads();
+    uint32_t* so = sorted + (size_t)j * s.items + lo;
+    for (uint32_t r = t; r < n; r += blockDim.x) so[atomicAdd(&cnt[rl[r]], 1u)] = ri[r];
+}
+
+// One block per window, LDS scan over the window's buckets (counts / offsets come from k_pip_binsort):
 //   segbase[b]  = exclusive prefix sum of the number of chunks each bucket touches (its segments)
 //   chunk_first[j][k] = the bucket that entry k L belongs to
 template <class C>
-__global__ void __launch_bounds__(1024) k_pip_scan(PipShape s, const uint32_t* __restrict__ counts,
-                                                   uint32_t* __restrict__ offsets, uint32_t* __restrict__ segbase,
-                                                   uint32_t* __restrict__ chunk_first, uint32_t* __restrict__ wtotal) {
+__global__ void __launch_bounds__(1024) k_pip_segments(PipShape s, const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ offsets, uint32_t* __restrict__ segbase,
+                                                       uint32_t* __restrict__ chunk_first) {
     __shared__ uint32_t part[1024];
     const uint32_t j = blockIdx.x, t = threadIdx.x;
     const uint32_t nb = s.nb(j), bb = s.bbase(j);
     const uint32_t per = (nb + blockDim.x - 1) / blockDim.x;
     const uint32_t lo = min(nb, t * per), hi = min(lo + per, nb);
-    const uint32_t* cj = counts + bb;
-    auto block_exclusive = [&](uint32_t sum) -> uint32_t {   // Hillis-Steele over the per-thread sums
-        part[t] = sum;
-        __syncthreads();
-        for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
-            uint32_t v = t >= d ? part[t - d] : 0;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
-        }
-        const uint32_t r = part[t] - sum;
-        __syncthreads();
-        return r;
-    };
-    uint32_t sum = 0;
-    for (uint32_t b = lo; b < hi; b++) sum += cj[b];
-    uint32_t run = block_exclusive(sum);
-    if (t == blockDim.x - 1) wtotal[j] = run + sum;
-    const uint32_t run0 = run;
     uint32_t nseg = 0;
     for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t cnt = cj[b];
-        offsets[bb + b] = run;
+        const uint32_t cnt = counts[bb + b], o = offsets[bb + b];
         if (cnt) {
-            nseg += (run + cnt - 1) / s.L - run / s.L + 1;
-            for (uint32_t k = (run + s.L - 1) / s.L; k * s.L < run + cnt; k++) chunk_first[(size_t)j * s.cpw + k] = b;
+            nseg += (o + cnt - 1) / s.L - o / s.L + 1;
+            for (uint32_t k = (o + s.L - 1) / s.L; k * s.L < o + cnt; k++) chunk_first[(size_t)j * s.cpw + k] = b;
         }
-        run += cnt;
     }
-    uint32_t srun = block_exclusive(nseg);
-    run = run0;
+    part[t] = nseg;
+    __syncthreads();
+    for (uint32_t d = 1; d < blockDim.x; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t srun = part[t] - nseg;
     for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t cnt = cj[b];
+        const uint32_t cnt = counts[bb + b], o = offsets[bb + b];
         segbase[bb + b] = srun;
-        if (cnt) srun += (run + cnt - 1) / s.L - run / s.L + 1;
-        run += cnt;
+        if (cnt) srun += (o + cnt - 1) / s.L - o / s.L + 1;
     }
-}
-
-// sorted: [W][items] (only the first wtotal[j] entries of each row are written)
-template <class C>
-__global__ void __launch_bounds__(256) k_pip_scatter(PipShape s, const uint32_t* __restrict__ keys,
-                                                     const uint32_t* __restrict__ slots,
-                                                     const uint32_t* __restrict__ offsets,
-                                                     uint32_t* __restrict__ sorted) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = blockIdx.y;
-    if (i >= s.items) return;
-    const uint32_t key = keys[(size_t)j * s.items + i];
-    if (key == PIP_EMPTY) return;
-    const uint32_t b = key >> 1;
-    sorted[(size_t)j * s.items + offsets[s.bbase(j) + b] + slots[(size_t)j * s.items + i]] = (i << 1) | (key & 1u);
 }
 
 // ---- bucket sums, chunk by chunk ------------------------------------------------------------------------------
@@ -622,8 +777,8 @@ __global__ void __launch_bounds__(64) k_pip_zero_point(uint32_t* __restrict__ ou
 }
 
 struct PipWorkspace {
-    size_t points, keys, slots, sorted, counts, offsets, segbase, chunk_first, wtotal, segs, buckets, tiles, wsums, hlist,
-        hcount, bad, total;
+    size_t points, split, rec_item, rec_low, sorted, ccount, cstart, ccursor, counts, offsets, segbase, chunk_first, wtotal, segs,
+        buckets, tiles, wsums, hlist, hcount, bad, total;
 };
 template <class C>
 inline PipWorkspace pip_workspace(const PipShape& s) {
@@ -634,12 +789,21 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     size_t o = 0;
     w.points = o;
     o += al(((size_t)s.items + 1) * 2 * N * 4);
-    w.keys = o;
+    w.split = o;
+    o += al((size_t)s.n * PIP_SPLIT_WORDS * 4);
+    w.rec_item = o;
     o += al((size_t)s.W * s.items * 4);
-    w.slots = o;
-    o += al((size_t)s.W * s.items * 4);
+    w.rec_low = o;
+    o += al((size_t)s.W * s.items * 2);
     w.sorted = o;
     o += al((size_t)s.W * s.items * 4 + 16);
+    const size_t ncb = pip_ncoarse_total(s);
+    w.ccount = o;
+    o += al(ncb * 4);
+    w.cstart = o;
+    o += al(ncb * 4);
+    w.ccursor = o;
+    o += al(ncb * 4);
     w.counts = o;
     o += al((size_t)s.nbuckets * 4);
     w.offsets = o;
@@ -680,12 +844,15 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     };
     const PipWorkspace w = pip_workspace<C>(s);
     auto at = [&](size_t off) { return reinterpret_cast<uint32_t*>(d_ws + off); };
-    uint32_t *points = at(w.points), *keys = at(w.keys), *slots = at(w.slots), *sorted = at(w.sorted);
+    uint32_t *points = at(w.points), *split = at(w.split), *rec_item = at(w.rec_item), *sorted = at(w.sorted);
+    uint16_t* rec_low = reinterpret_cast<uint16_t*>(d_ws + w.rec_low);
+    uint32_t *ccount = at(w.ccount), *cstart = at(w.cstart), *ccursor = at(w.ccursor);
     uint32_t *counts = at(w.counts), *offsets = at(w.offsets), *segbase = at(w.segbase), *chunk_first = at(w.chunk_first);
     uint32_t *wtotal = at(w.wtotal), *segs = at(w.segs), *buckets = at(w.buckets), *tiles = at(w.tiles);
     uint32_t *wsums = at(w.wsums), *hlist = at(w.hlist), *hcount = at(w.hcount);
     uint32_t* bad = d_status ? d_status : at(w.bad);
-    hipError_t e = zero_words_async(counts, (size_t)s.nbuckets * 4, st);
+    const uint32_t ncb = pip_ncoarse_total(s);
+    hipError_t e = zero_words_async(ccount, (size_t)ncb * 4, st);
     if (e != hipSuccess) return e;
     e = zero_words_async(hcount, 8, st);   // hcount and the private `bad` word behind it
     if (e != hipSuccess) return e;
@@ -694,10 +861,14 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
         if (e != hipSuccess) return e;
     }
     mark(0);
-    hipLaunchKernelGGL(k_pip_points<C>, dim3((s.n + 127) / 128), dim3(128), 0, st, s, d_wire_points, points, bad);
-    hipLaunchKernelGGL(k_pip_digits<C>, dim3((s.n + 255) / 256), dim3(256), 0, st, s, d_scalars, keys, slots, counts);
-    hipLaunchKernelGGL(k_pip_scan<C>, dim3(s.W), dim3(1024), 0, st, s, counts, offsets, segbase, chunk_first, wtotal);
-    hipLaunchKernelGGL(k_pip_scatter<C>, dim3((s.items + 255) / 256, s.W), dim3(256), 0, st, s, keys, slots, offsets, sorted);
+    hipLaunchKernelGGL(k_pip_points<C>, dim3((s.n + 127) / 128), dim3(128), 0, st, s, d_wire_points, d_scalars, points, split, bad);
+    const dim3 cgrid((s.n + PIP_CHUNK - 1) / PIP_CHUNK, s.W);
+    hipLaunchKernelGGL(k_pip_count<C>, cgrid, dim3(256), 0, st, s, split, ccount);
+    hipLaunchKernelGGL(k_pip_cscan, dim3(1), dim3(256), 0, st, s, ccount, cstart, ccursor, wtotal);
+    hipLaunchKernelGGL(k_pip_place<C>, cgrid, dim3(256), 0, st, s, split, cstart, ccursor, rec_item, rec_low);
+    hipLaunchKernelGGL(k_pip_binsort<C>, dim3(ncb), dim3(PIP_FINE_MAX), 0, st, s, ccount, cstart, rec_item, rec_low, counts, offsets,
+                       sorted);
+    hipLaunchKernelGGL(k_pip_segments<C>, dim3(s.W), dim3(1024), 0, st, s, counts, offsets, segbase, chunk_first);
     mark(1);
     const uint32_t bpw = (s.cpw + PIP_BLOCK - 1) / PIP_BLOCK;
     hipLaunchKernelGGL(k_pip_chunks<C>, dim3(s.W * bpw), dim3(PIP_BLOCK), pip_ring_bytes<C>(), st, s, points, sorted,
