@@ -794,7 +794,7 @@ def main():
             pass
         torch.cuda.empty_cache()
 
-    def side_leg(curve, n_, m_, batch, window_bits, steps):
+    def side_leg(curve, n_, m_, batch, window_bits, steps, lat_steps=0):
         """the same pass on another curve / shape: fresh engine, GPU-proved distinct proofs, verdicts checked"""
         a_o = B.Arith.init(curve, local_rank)
         pk_o = B.PublicKey.new(a_o, n_ * m_)
@@ -854,6 +854,16 @@ def main():
                "stage_ms": {k: round(v, 4) for k, v in ost.items()}, "blocks_per_proof": obpp,
                "tamper_check": {"tampered": int(Kt), "verdicts_exact": True},
                "roofline": verify_roofline(curve, n_, m_, batch, window_bits, ost["fixed_msm"], (a_o.PW - 1) // 2 * 8, launches=steps)}
+        if lat_steps > 0:   # one proof alone on this engine (B = 1 latency)
+            bv_o.run_device(d_pts_o.data_ptr(), d_sc_o.data_ptr(), 1, d_ok_o.data_ptr(), d_ws_o.data_ptr(), wsb_o, stream)
+            torch.cuda.synchronize()
+            bv_o.set_profiling(True)
+            ldt = timed(lambda i: bv_o.run_device(d_pts_o.data_ptr(), d_sc_o.data_ptr(), 1, d_ok_o.data_ptr(), d_ws_o.data_ptr(),
+                                                  wsb_o, stream), lat_steps, torch, None, dev)
+            lst_o, _, _ = bv_o.profile()
+            bv_o.set_profiling(False)
+            assert int(d_ok_o[:1].item()) == 0
+            res["latency_B=1"] = {"ms": ldt / lat_steps * 1e3, "stage_ms": {k: round(v, 4) for k, v in lst_o.items()}}
         bv_o.close()
         del d_ws_o, d_pts_o, d_sc_o, d_sc_b
         torch.cuda.empty_cache()
@@ -876,7 +886,10 @@ def main():
         release_main()
         for oc in ("ed25519", "secp256k1"):
             # 253-bit group order: 15 windows at c = 17 against 16 at c = 16 (123 GB of tables); 256 bits need 16 either way
-            others[oc] = side_leg(oc, n, m, Bsz, 17 if oc == "ed25519" else 16, args.other_curves_steps)
+            others[oc] = side_leg(oc, n, m, Bsz, 17 if oc == "ed25519" else 16, args.other_curves_steps,
+                                  lat_steps=args.latency_steps if world == 1 else 0)
+            # BASELINE.json's C3 shape on this curve (4 096 x (64,1), c = 16)
+            others[oc]["c3"] = side_leg(oc, 64, 1, 4096, 16, max(args.other_curves_steps, 3))
             others[oc]["parity"] = ("unpinned: not a reference backend; the prime-order subgroup of the curve under Ristretto255"
                                     if oc == "ed25519" else "the reference's second in-tree backend (not wired to its range proof)")
 

@@ -68,6 +68,7 @@ struct PipShape {
     uint32_t tw, tn, ntiles;   // tiles of a wide / narrow signed window, all tiles
     uint32_t L, cpw, capseg;   // entries per chunk, chunks per window, segment slots per window
     uint32_t fb;               // log2 of the buckets per coarse bin of the sort (5..8)
+    uint32_t fl;               // lanes per bucket in k_pip_fold (1, 2, 4 or 8)
     uint32_t bias[10];         // sum over the signed windows of half their range at their offset
 
     __host__ __device__ uint32_t width(uint32_t j) const { return q + (j < nwide ? 1u : 0u); }
@@ -138,6 +139,12 @@ inline int pip_shape(size_t n, int c, bool glv, const uint32_t* max_words, int b
     s.fb = fb;
     s.cpw = (s.items + L - 1) / L;
     s.capseg = s.cpw + s.nbmax;
+    // k_pip_fold: a bucket touches about (its entries / L) + 1 chunks; while the launch stays within one residency of the
+    // chip, several lanes share a bucket's segments (strided sums, then a butterfly inside the lane group)
+    const size_t nseg = entries / ((size_t)s.nbuckets * L) + 1;
+    uint32_t fl = 1;
+    while (fl < 8 && 2 * fl <= nseg && (size_t)s.nbuckets * 2 * fl <= ((size_t)1 << 18)) fl <<= 1;
+    s.fl = fl;
     return BPP_OK;
 }
 
@@ -431,7 +438,15 @@ __global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const 
     const uint16_t* rl = rec_low + (size_t)j * s.items + lo;
     cnt[t] = 0;
     __syncthreads();
-    for (uint32_t r = t; r < n; r += blockDim.x) atomicAdd(&cnt[rl[r]], 1u);
+    // four records per thread per step: the loads of a step are in flight together
+    for (uint32_t r = t; r < n; r += 4 * blockDim.x) {
+        uint32_t lw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lw[u] = r + u * blockDim.x < n ? rl[r + u * blockDim.x] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (lw[u] != 0xffffffffu) atomicAdd(&cnt[lw[u]], 1u);
+    }
     __syncthreads();
     // exclusive scan of cnt (Hillis-Steele)
     const uint32_t mine = cnt[t];
@@ -452,7 +467,18 @@ __global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const 
     cnt[t] = ex;   // cursors
     __syncthreads();
     uint32_t* so = sorted + (size_t)j * s.items + lo;
-    for (uint32_t r = t; r < n; r += blockDim.x) so[atomicAdd(&cnt[rl[r]], 1u)] = ri[r];
+    for (uint32_t r = t; r < n; r += 4 * blockDim.x) {
+        uint32_t lw[4], it[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = r + u * blockDim.x < n;
+            lw[u] = in ? rl[r + u * blockDim.x] : 0xffffffffu;
+            it[u] = in ? ri[r + u * blockDim.x] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (lw[u] != 0xffffffffu) so[atomicAdd(&cnt[lw[u]], 1u)] = it[u];
+    }
 }
 
 // One block per window, LDS scan over the window's buckets (counts / offsets come from k_pip_binsort):
@@ -596,7 +622,8 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// one lane per bucket: buckets[flat] = sum of the bucket's segments (infinity for an empty bucket)
+// s.fl lanes per bucket (consecutive lanes of one wave): buckets[flat] = sum of the bucket's segments (infinity for an
+// empty bucket).  Lane `sub` of the group adds segments sub, sub + fl, ..; a butterfly inside the group adds the lanes.
 template <class C>
 __global__ void __launch_bounds__(128) k_pip_fold(PipShape s, const uint32_t* __restrict__ offsets,
                                                   const uint32_t* __restrict__ counts,
@@ -604,25 +631,28 @@ __global__ void __launch_bounds__(128) k_pip_fold(PipShape s, const uint32_t* __
                                                   uint32_t* __restrict__ buckets, uint32_t* __restrict__ heavy_list,
                                                   uint32_t* __restrict__ heavy_count) {
     constexpr int JW = jac_words<C>();
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= s.nbuckets) return;
-    const uint32_t cnt = counts[gid];
+    const uint32_t th = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = th / s.fl, sub = th % s.fl;
+    const bool live = gid < s.nbuckets;
+    const uint32_t cnt = live ? counts[gid] : 0u;
     Jac<C> acc = jac_inf<C>();
+    bool heavy = false;
     if (cnt) {
         const uint32_t o = offsets[gid];
         const uint32_t nseg = (o + cnt - 1) / s.L - o / s.L + 1;
         if (nseg > PIP_FOLD_MAX) {
-            heavy_list[atomicAdd(heavy_count, 1u)] = gid;
-            return;
+            heavy = true;
+            if (sub == 0) heavy_list[atomicAdd(heavy_count, 1u)] = gid;
+        } else {
+            // window of the bucket: the wide windows come first
+            const uint32_t wide = s.nwide << s.q;
+            const uint32_t j = gid < wide ? gid >> s.q : min(s.nwide + ((gid - wide) >> (s.q - 1)), s.W - 1);
+            const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * JW;
+            for (uint32_t t = sub; t < nseg; t += s.fl) acc = jac_add(acc, jac_ldg<C>(sp + (size_t)t * JW));
         }
-        // window of the bucket: the wide windows come first
-        const uint32_t wide = s.nwide << s.q;
-        const uint32_t j = gid < wide ? gid >> s.q : min(s.nwide + ((gid - wide) >> (s.q - 1)), s.W - 1);
-        const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * JW;
-        acc = jac_ldg<C>(sp);
-        for (uint32_t t = 1; t < nseg; t++) acc = jac_add(acc, jac_ldg<C>(sp + (size_t)t * JW));
     }
-    jac_stg<C>(buckets + (size_t)gid * JW, acc);
+    if (s.fl > 1) acc = wave_sum_jac<C>(acc, (int)s.fl);   // every lane of the wave takes part
+    if (live && sub == 0 && !heavy) jac_stg<C>(buckets + (size_t)gid * JW, acc);
 }
 
 // one wave per bucket of the heavy list (grid-stride): lanes sum every 64th segment, a butterfly adds the lanes
@@ -874,7 +904,7 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     hipLaunchKernelGGL(k_pip_chunks<C>, dim3(s.W * bpw), dim3(PIP_BLOCK), pip_ring_bytes<C>(), st, s, points, sorted,
                        offsets, counts, segbase, chunk_first, wtotal, segs);
     mark(2);
-    hipLaunchKernelGGL(k_pip_fold<C>, dim3((s.nbuckets + 127) / 128), dim3(128), 0, st, s, offsets, counts, segbase, segs,
+    hipLaunchKernelGGL(k_pip_fold<C>, dim3((unsigned)(((size_t)s.nbuckets * s.fl + 127) / 128)), dim3(128), 0, st, s, offsets, counts, segbase, segs,
                        buckets, hlist, hcount);
     // buckets spread over many chunks are few (none at all for uniformly distributed digits): a small grid that strides
     // over the list
