@@ -63,7 +63,7 @@ FR_BITS = {"bls12_381": 255, "secp256k1": 256, "ed25519": 253}
 def loop_peaks(curve):
     """(G mixed additions/s of the register-resident loop, T v_mad_u64_u32 lane-ops/s, source file) recorded by
     tools/ubench.hip on this GPU model under profiles/ -- not measured in this run"""
-    for cand in ("ubench_r02.json", "ubench_r01_final.json"):
+    for cand in ("ubench_r03.json", "ubench_r02.json", "ubench_r01_final.json"):
         try:
             uj = json.load(open(os.path.join(ROOT, "profiles", cand)))
             key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}.get(curve)
@@ -1050,9 +1050,19 @@ def main():
                "workload": "one MulVec of N full-width scalars x N distinct points, all in HBM; result checked against the points' discrete logs",
                "curves": {}}
         try:
-            uj = json.load(open(os.path.join(ROOT, "profiles", "ubench_r02.json")))
+            uj = json.load(open(os.path.join(ROOT, "profiles", "ubench_r03.json")))
         except Exception:
             uj = {}
+        def msm_traffic(curve_, lg_):
+            # HBM bytes per launch of the dominant kernel (k_pip_chunks) from the recorded PMC profile, where one exists
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_pip_chunks.json")))
+                if pj.get("curve") == curve_ and pj.get("log2n") == lg_:
+                    return pj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+            return None
+
         for mc in ("bls12_381", "secp256k1", "ed25519"):
             a_m = B.Arith.init(mc, local_rank)
             order = MSM_ORDER[mc]
@@ -1105,7 +1115,7 @@ def main():
                                           "algorithmic_bytes": alg, "kernel_ms": kern_ms,
                                           "achieved": alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
                                           "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kern_ms > 0 else 0.0,
-                                          "traffic": None,
+                                          "traffic": msm_traffic(mc, lg),
                                           "alu": {"unit": "G mixed additions/s", "kernel": "k_pip_chunks", "additions": madds,
                                                   "additions_per_point": madds / N, "achieved": add_rate, "peak": loop_peak,
                                                   "frac": (add_rate / loop_peak) if loop_peak else None,
@@ -1116,7 +1126,7 @@ def main():
         msm["value"] = msm["curves"]["bls12_381"][-1]["value"]
         msm["note"] = ("value = the largest BLS12-381 point; roofline.achieved = N x (affine point + scalar) bytes / the summed stage "
                        "time of one call (HIP events on the launch stream) -- integer-ALU bound like the verifier; alu = bucket additions "
-                       "per second of k_pip_chunks against the register-resident loop of the same addition (profiles/ubench_r02.json)")
+                       "per second of k_pip_chunks against the register-resident loop of the same addition (profiles/ubench_r03.json)")
 
     if rank == 0:
         N_msm = msm_len_main
@@ -1135,7 +1145,7 @@ def main():
         add_rate = adds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         add_peak = mad_peak = None
         peak_file = None
-        for cand in ("ubench_r02.json", "ubench_r01_final.json"):
+        for cand in ("ubench_r03.json", "ubench_r02.json", "ubench_r01_final.json"):
             try:
                 uj = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}[args.curve]
