@@ -15,7 +15,8 @@ prof() {  # name, bench args...
     echo "done $name"
 }
 if [ "$PART" = all ] || [ "$PART" = 1 ]; then
-    prof headline $OFF --latency-steps 5 --combined-steps 10 || exit 1
+    prof headline $OFF || exit 1                      # k_fixed_msm<..., 0>: only launches at the bench geometry
+    prof latency_combined $OFF --latency-steps 5 --combined-steps 10 || exit 1
     prof c3 --config c3 $OFF --combined-steps 5 || exit 1
     prof prove_serialized_production $OFF --prove-steps 2 --serialized-steps 3 --production-steps 3 || exit 1
     prof msm $OFF --steps 2 --warmup 1 --msm-steps 5 || exit 1
