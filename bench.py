@@ -680,6 +680,40 @@ def main():
                       "note": "input = the versioned proof container + compressed commitments (include/bpp_amd.h), already in "
                               "HBM; decode (square root, G1 subgroup check, canonicity) + verification; `from_pinned_host` "
                               "adds the PCIe copy of those bytes.  Engine data format: the reference never serializes"}
+        # the same batch in container version 2 (uncompressed points: no square root at decode time, +48 bytes per point)
+        if B.uncompressed_bytes(a):
+            blobs2 = B.encode_proofs(a, n, m, pts_, scs[:D] if D < Bsz else scs, version=2)
+            comm2 = B.uncompressed_points(a, V_.reshape(-1, a.PW)).reshape(D, m, -1)
+            if D < Bsz:
+                blobs2, comm2 = blobs2[np.arange(Bsz) % D], comm2[np.arange(Bsz) % D]
+            d_bl2 = torch.from_numpy(np.ascontiguousarray(blobs2)).to(dev)
+            d_cm2 = torch.from_numpy(np.ascontiguousarray(comm2)).to(dev)
+
+            def sstep2(_i):
+                bv.verify_serialized_device(d_bl2.data_ptr(), d_cm2.data_ptr(), Bsz, d_sok.data_ptr(), d_sws.data_ptr(), swsb,
+                                            stream, uncompressed=True)
+            sstep2(0)
+            bv.set_profiling(True)
+            sdt2 = timed(sstep2, args.serialized_steps, torch, dist, coll_dev)
+            sst2, _, _ = bv.profile()
+            bv.set_profiling(False)
+            assert int(d_sok.cpu().numpy().sum()) == 0, "a valid version-2 container failed to verify"
+            bl2_bad = np.ascontiguousarray(blobs2).copy()
+            ub_ = comm2.shape[2]
+            bl2_bad[1, 12 + ub_ - 1] ^= 1               # y of A: off the curve
+            bl2_bad[2, 12 + (3 + 2 * ((n * m).bit_length() - 1)) * ub_ + 32] ^= 1   # s' off by one
+            d_bl2b = torch.from_numpy(bl2_bad).to(dev)
+            d_sok.fill_(7)
+            bv.verify_serialized_device(d_bl2b.data_ptr(), d_cm2.data_ptr(), Bsz, d_sok.data_ptr(), d_sws.data_ptr(), swsb, stream,
+                                        uncompressed=True)
+            torch.cuda.synchronize()
+            g2 = d_sok.cpu().numpy()
+            assert g2[1] == 2 and g2[2] == 1 and int((g2 != 0).sum()) == 2, "version-2 containers: wrong statuses"
+            serialized["uncompressed_container"] = {
+                "value": world * Bsz * args.serialized_steps / sdt2, "unit": "verifies/s", "ms_per_step": sdt2 / args.serialized_steps * 1e3,
+                "bytes_per_proof": int(blobs2.shape[1] + m * ub_), "decode_ms": sdt2 / args.serialized_steps * 1e3 - sum(sst2.values()),
+                "note": "container version 2: uncompressed points (no square root at decode time)"}
+            del d_bl2, d_cm2, d_bl2b
         del d_sws, d_bl, d_cm
 
     # ---- secondary, separately timed: the combined batch check (engine mode, not the reference's per-proof

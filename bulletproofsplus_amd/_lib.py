@@ -36,7 +36,8 @@ EXPORTS = [
     "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
     "bpp_verifier_derive_challenges", "bpp_range_prove_batch_fs", "bpp_range_prove_batch_fs_device",
     "bpp_point_compressed_bytes", "bpp_points_compress", "bpp_points_decompress", "bpp_points_decompress_device",
-    "bpp_range_verify_batch_compressed", "bpp_proof_bytes", "bpp_proofs_encode", "bpp_proofs_decode",
+    "bpp_range_verify_batch_compressed", "bpp_proof_bytes", "bpp_proofs_encode", "bpp_proofs_decode", "bpp_point_uncompressed_bytes", "bpp_points_uncompressed",
+    "bpp_proof_bytes_version", "bpp_proofs_encode_version",
     "bpp_range_verify_batch_serialized", "bpp_verifier_serialized_workspace_bytes",
     "bpp_range_verify_batch_serialized_device",
 ]
@@ -120,6 +121,12 @@ def lib():
         L.bpp_proof_bytes.argtypes = [i32, sz, sz]
         L.bpp_proof_bytes.restype = sz
         L.bpp_proofs_encode.argtypes = [vp, sz, sz, vp, vp, sz, vp]
+        L.bpp_point_uncompressed_bytes.argtypes = [i32]
+        L.bpp_point_uncompressed_bytes.restype = sz
+        L.bpp_points_uncompressed.argtypes = [vp, vp, sz, vp]
+        L.bpp_proof_bytes_version.argtypes = [i32, sz, sz, i32]
+        L.bpp_proof_bytes_version.restype = sz
+        L.bpp_proofs_encode_version.argtypes = [vp, sz, sz, i32, vp, vp, sz, vp]
         L.bpp_proofs_decode.argtypes = [vp, sz, sz, vp, sz, vp, vp, vp]
         L.bpp_range_verify_batch_serialized.argtypes = [vp, vp, vp, sz, i32, vp]
         L.bpp_verifier_serialized_workspace_bytes.argtypes = [vp, sz]

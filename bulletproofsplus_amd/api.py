@@ -239,20 +239,34 @@ def decompress_points(arith: Arith, data):
     return pts, ok
 
 
-def proof_bytes(arith: Arith, n: int, m: int) -> int:
-    """bytes of one serialized proof (include/bpp_amd.h, "the container")"""
-    return _lib.lib().bpp_proof_bytes(arith.curve, n, m)
+def proof_bytes(arith: Arith, n: int, m: int, version: int = 1) -> int:
+    """bytes of one serialized proof (include/bpp_amd.h, "the container"); version 2 = uncompressed points"""
+    return _lib.lib().bpp_proof_bytes_version(arith.curve, n, m, version)
 
 
-def encode_proofs(arith: Arith, n: int, m: int, points, scalars) -> np.ndarray:
+def uncompressed_bytes(arith: Arith) -> int:
+    """bytes of one uncompressed point (96 BLS12-381 G1, 65 secp256k1 SEC1; 0 = not offered)"""
+    return _lib.lib().bpp_point_uncompressed_bytes(arith.curve)
+
+
+def uncompressed_points(arith: Arith, points) -> np.ndarray:
+    """wire points (n, PW) u64 -> (n, uncompressed_bytes) u8: the point encoding of container version 2"""
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, arith.PW)
+    out = np.zeros((pts.shape[0], uncompressed_bytes(arith)), dtype=np.uint8)
+    check(_lib.lib().bpp_points_uncompressed(arith.handle, _ptr(pts), pts.shape[0], _ptr(out)), "bpp_points_uncompressed")
+    return out
+
+
+def encode_proofs(arith: Arith, n: int, m: int, points, scalars, version: int = 1) -> np.ndarray:
     """points (count, 3+2k, PW), scalars (count, 3, 4) -> (count, proof_bytes) u8.  No reference counterpart."""
     k = (n * m).bit_length() - 1
     pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3 + 2 * k, arith.PW)
     sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 3, 4)
     if sc.shape[0] != pts.shape[0]:
         raise RuntimeError("encode_proofs: one scalar triple per proof")
-    out = np.zeros((pts.shape[0], proof_bytes(arith, n, m)), dtype=np.uint8)
-    check(_lib.lib().bpp_proofs_encode(arith.handle, n, m, _ptr(pts), _ptr(sc), pts.shape[0], _ptr(out)), "bpp_proofs_encode")
+    out = np.zeros((pts.shape[0], proof_bytes(arith, n, m, version)), dtype=np.uint8)
+    check(_lib.lib().bpp_proofs_encode_version(arith.handle, n, m, version, _ptr(pts), _ptr(sc), pts.shape[0], _ptr(out)),
+          "bpp_proofs_encode_version")
     return out
 
 
@@ -506,17 +520,18 @@ class BatchVerifier:
               "bpp_range_verify_batch_compressed")
         return ok
 
-    def verify_serialized(self, proofs, commitments, transcript: bool = False) -> np.ndarray:
+    def verify_serialized(self, proofs, commitments, transcript: bool = False, uncompressed: bool = False) -> np.ndarray:
         """proofs (count, proof_bytes) u8, commitments (count, m, compressed_bytes) u8 -> status (count,) u32:
-        0 Ok / 1 VerificationError / 2 FormatError"""
-        pb = proof_bytes(self.arith, self.n, self.m)
+        0 Ok / 1 VerificationError / 2 FormatError.  uncompressed: container version 2 (and uncompressed commitments)"""
+        pb = proof_bytes(self.arith, self.n, self.m, 2 if uncompressed else 1)
         raw = np.ascontiguousarray(proofs, dtype=np.uint8).reshape(-1, pb)
-        cm = np.ascontiguousarray(commitments, dtype=np.uint8).reshape(-1, self.m, compressed_bytes(self.arith))
+        cm = np.ascontiguousarray(commitments, dtype=np.uint8).reshape(
+            -1, self.m, uncompressed_bytes(self.arith) if uncompressed else compressed_bytes(self.arith))
         if cm.shape[0] != raw.shape[0]:
             raise RuntimeError("verify_serialized: m commitments per proof")
         ok = np.zeros(raw.shape[0], dtype=np.uint32)
         check(_lib.lib().bpp_range_verify_batch_serialized(self.handle, _ptr(raw), _ptr(cm), raw.shape[0],
-                                                           1 if transcript else 0, _ptr(ok)),
+                                                           (1 if transcript else 0) | (2 if uncompressed else 0), _ptr(ok)),
               "bpp_range_verify_batch_serialized")
         return ok
 
@@ -524,11 +539,11 @@ class BatchVerifier:
         return _lib.lib().bpp_verifier_serialized_workspace_bytes(self.handle, count)
 
     def verify_serialized_device(self, d_proofs: int, d_commitments: int, count: int, d_ok: int, d_workspace: int,
-                                 workspace_bytes: int, stream: int = 0, transcript: bool = False):
+                                 workspace_bytes: int, stream: int = 0, transcript: bool = False, uncompressed: bool = False):
         """verify_serialized with every buffer in HBM (raw device pointers), asynchronous on `stream`: containers and
-        compressed commitments in, per-proof status words (0 / 1 / 2) out"""
+        compressed (version 2: uncompressed) commitments in, per-proof status words (0 / 1 / 2) out"""
         check(_lib.lib().bpp_range_verify_batch_serialized_device(self.handle, d_proofs, d_commitments, count,
-                                                                  1 if transcript else 0, d_ok, d_workspace,
+                                                                  (1 if transcript else 0) | (2 if uncompressed else 0), d_ok, d_workspace,
                                                                   workspace_bytes, stream or None),
               "bpp_range_verify_batch_serialized_device")
 

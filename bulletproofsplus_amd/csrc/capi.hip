@@ -645,33 +645,80 @@ inline bool scalar_is_canonical(int curve, const uint8_t* b) {
 }
 }  // namespace
 
-extern "C" size_t bpp_proof_bytes(int curve_id, size_t n, size_t m) {
-    const size_t cb = bpp_point_compressed_bytes(curve_id);
+extern "C" size_t bpp_point_uncompressed_bytes(int curve_id) {
+    switch (curve_id) {
+        case BPP_BLS12_381_G1: return 96;
+        case BPP_SECP256K1: return 65;
+        default: return 0;   /* ristretto255 has no uncompressed form */
+    }
+}
+static size_t container_point_size(int curve_id, int version) {
+    return version == 2 ? bpp_point_uncompressed_bytes(curve_id) : (version == 1 ? bpp_point_compressed_bytes(curve_id) : 0);
+}
+extern "C" size_t bpp_proof_bytes_version(int curve_id, size_t n, size_t m, int version) {
+    const size_t cb = container_point_size(curve_id, version);
     const size_t mn = n * m;
     if (cb == 0 || mn == 0 || (mn & (mn - 1))) return 0;
     return BPP_HDR + (3 + 2 * (size_t)log2_exact(mn)) * cb + 96;
 }
+extern "C" size_t bpp_proof_bytes(int curve_id, size_t n, size_t m) { return bpp_proof_bytes_version(curve_id, n, m, 1); }
 
-extern "C" int bpp_proofs_encode(bpp_ctx* ctx, size_t n, size_t m, const uint64_t* points, const uint64_t* scalars,
-                                 size_t count, uint8_t* out) {
+// wire points -> uncompressed bytes (host: a change of byte order)
+static void points_to_uncompressed(int curve, const uint64_t* points, size_t n, uint8_t* out) {
+    const size_t pw = (size_t)bpp_point_words(curve), L = (pw - 1) / 2, ub = bpp_point_uncompressed_bytes(curve);
+    const size_t off = curve == BPP_SECP256K1 ? 1 : 0, fb = L * 8;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t* w = points + i * pw;
+        uint8_t* o = out + i * ub;
+        std::memset(o, 0, ub);
+        if (w[2 * L]) {
+            if (curve == BPP_BLS12_381_G1) o[0] = 0x40;
+            continue;
+        }
+        if (curve == BPP_SECP256K1) o[0] = 0x04;
+        for (size_t b = 0; b < fb; b++) {
+            const size_t k = fb - 1 - b;
+            o[off + b] = (uint8_t)(w[k >> 3] >> (8 * (k & 7)));
+            o[off + fb + b] = (uint8_t)(w[L + (k >> 3)] >> (8 * (k & 7)));
+        }
+    }
+}
+extern "C" int bpp_points_uncompressed(bpp_ctx* ctx, const uint64_t* points, size_t n, uint8_t* out) {
+    if (!ctx || (n && (!points || !out))) return fail(BPP_E_ARG, "null argument");
+    if (bpp_point_uncompressed_bytes(ctx->curve) == 0) return fail(BPP_E_ARG, "no uncompressed form for this curve");
+    points_to_uncompressed(ctx->curve, points, n, out);
+    return BPP_OK;
+}
+
+extern "C" int bpp_proofs_encode_version(bpp_ctx* ctx, size_t n, size_t m, int version, const uint64_t* points,
+                                         const uint64_t* scalars, size_t count, uint8_t* out) {
     if (!ctx || (count && (!points || !scalars || !out))) return fail(BPP_E_ARG, "null argument");
-    const size_t pb = bpp_proof_bytes(ctx->curve, n, m);
-    if (pb == 0 || n > 255 || m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255)");
+    const size_t pb = bpp_proof_bytes_version(ctx->curve, n, m, version);
+    if (pb == 0 || n > 255 || m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255); version 1 or 2");
     if (count == 0) return BPP_OK;
-    const size_t cb = bpp_point_compressed_bytes(ctx->curve);
+    const size_t cb = container_point_size(ctx->curve, version);
     const uint32_t k = log2_exact(n * m);
     const size_t npp = 3 + 2 * (size_t)k;
     std::vector<uint8_t> comp(count * npp * cb);
-    int rc = bpp_points_compress(ctx, points, count * npp, comp.data());
-    if (rc) return rc;
+    if (version == 2) {
+        points_to_uncompressed(ctx->curve, points, count * npp, comp.data());
+    } else {
+        int rc = bpp_points_compress(ctx, points, count * npp, comp.data());
+        if (rc) return rc;
+    }
     for (size_t p = 0; p < count; p++) {
         uint8_t* o = out + p * pb;
-        const uint8_t hdr[BPP_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)ctx->curve, (uint8_t)n, (uint8_t)m, (uint8_t)k, 0, 0, 0};
+        const uint8_t hdr[BPP_HDR] = {'B', 'P', 'P', '+', (uint8_t)version, (uint8_t)ctx->curve, (uint8_t)n, (uint8_t)m, (uint8_t)k, 0, 0, 0};
         std::memcpy(o, hdr, BPP_HDR);
         std::memcpy(o + BPP_HDR, comp.data() + p * npp * cb, npp * cb);
         std::memcpy(o + BPP_HDR + npp * cb, scalars + p * 12, 96);   // little-endian host: the u64 limbs are the bytes
     }
     return BPP_OK;
+}
+
+extern "C" int bpp_proofs_encode(bpp_ctx* ctx, size_t n, size_t m, const uint64_t* points, const uint64_t* scalars,
+                                 size_t count, uint8_t* out) {
+    return bpp_proofs_encode_version(ctx, n, m, 1, points, scalars, count, out);
 }
 
 // decode to device buffers: d_points count x (3 + 2k) wire points, status[p] = 0 / BPP_FORMAT_ERROR (host vector)
@@ -740,28 +787,33 @@ extern "C" size_t bpp_verifier_serialized_workspace_bytes(const bpp_verifier* v,
 }
 
 extern "C" int bpp_range_verify_batch_serialized_device(bpp_verifier* v, const void* d_proofs, const void* d_commitments,
-                                                        size_t count, int transcript, uint32_t* d_ok, void* d_workspace,
+                                                        size_t count, int flags, uint32_t* d_ok, void* d_workspace,
                                                         size_t workspace_bytes, void* stream) {
     if (!v || !d_proofs || !d_commitments || !d_ok || !d_workspace) return fail(BPP_E_ARG, "null argument");
+    if (flags & ~(BPP_SER_TRANSCRIPT | BPP_SER_UNCOMPRESSED)) return fail(BPP_E_ARG, "unknown flag");
+    const int transcript = flags & BPP_SER_TRANSCRIPT;
+    const uint32_t version = (flags & BPP_SER_UNCOMPRESSED) ? 2u : 1u;
     if (count == 0) return BPP_OK;
     if (count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count too large for one launch");
     HIPCHK(hipSetDevice(v->ctx.device));
     return dispatch(v->ctx.curve, [&](auto cv) -> int {
         return VerifyImpl<decltype(cv)>::run_serialized(v, static_cast<const uint8_t*>(d_proofs),
                                                         static_cast<const uint8_t*>(d_commitments), count, transcript != 0,
-                                                        d_ok, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                                                        d_ok, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                                                        version);
     });
 }
 
 // host buffers in, host verdicts out: the device path above between two copies
 extern "C" int bpp_range_verify_batch_serialized(bpp_verifier* v, const uint8_t* proofs, const uint8_t* commitments,
-                                                 size_t count, int transcript, uint32_t* out_ok) {
+                                                 size_t count, int flags, uint32_t* out_ok) {
     if (!v || !proofs || !commitments || !out_ok) return fail(BPP_E_ARG, "null argument");
     if (count == 0) return BPP_OK;
     HIPCHK(hipSetDevice(v->ctx.device));
     const VerifyShape& s = v->s;
-    const size_t pb = bpp_proof_bytes(v->ctx.curve, s.n, s.m);
-    const size_t cb = bpp_point_compressed_bytes(v->ctx.curve);
+    const int version = (flags & BPP_SER_UNCOMPRESSED) ? 2 : 1;
+    const size_t pb = bpp_proof_bytes_version(v->ctx.curve, s.n, s.m, version);
+    const size_t cb = container_point_size(v->ctx.curve, version);
     if (pb == 0 || s.n > 255 || s.m > 255) return fail(BPP_E_ARG, "n*m must be a power of two (n, m <= 255)");
     DevBuf dpr, dcm, dok, dws;
     const size_t wsb = bpp_verifier_serialized_workspace_bytes(v, count);
@@ -771,7 +823,7 @@ extern "C" int bpp_range_verify_batch_serialized(bpp_verifier* v, const uint8_t*
     HIPCHK(dws.alloc(wsb));
     HIPCHK(hipMemcpy(dpr.p, proofs, count * pb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dcm.p, commitments, count * s.m * cb, hipMemcpyHostToDevice));
-    int rc = bpp_range_verify_batch_serialized_device(v, dpr.p, dcm.p, count, transcript, dok.u32(), dws.p, wsb, nullptr);
+    int rc = bpp_range_verify_batch_serialized_device(v, dpr.p, dcm.p, count, flags, dok.u32(), dws.p, wsb, nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(out_ok, dok.p, count * 4, hipMemcpyDeviceToHost));
     return BPP_OK;

@@ -32,6 +32,19 @@ constexpr int compressed_bytes() {
     return C::ID == 0 ? 48 : (C::ID == 1 ? 33 : 32);
 }
 
+// Version 2 of the container carries UNCOMPRESSED points: no square root at decode time (a third of the decoder's
+// arithmetic) for 48 / 32 more bytes per point.  BLS12-381 G1: 96 bytes, x | y big-endian, byte 0 bit 7 = 0 (not
+// compressed), bit 6 = infinity (then everything else zero), bit 5 = 0 (ZCash / IETF uncompressed form); secp256k1: SEC1
+// 0x04 | x | y, 65 bytes, infinity = 65 zero bytes.  ristretto255 has no such form: version 1 only.
+template <class C>
+constexpr int uncompressed_bytes() {
+    return C::ID == 0 ? 96 : (C::ID == 1 ? 65 : 0);
+}
+template <class C>
+__host__ __device__ constexpr int container_point_bytes(uint32_t version) {
+    return version == 2 ? uncompressed_bytes<C>() : compressed_bytes<C>();
+}
+
 // a^((p+1)/4): the square root of a quadratic residue when p = 3 mod 4; the caller checks the result by squaring.
 // Fixed 2-bit windows over the public constant P::SQRTW, most significant first, with the three table entries a, a^2,
 // a^3 in REGISTERS: the exponent is the same in every lane, so the window digit is wave-uniform and the entry is picked
@@ -208,6 +221,61 @@ __device__ bool point_decompress(const uint8_t* __restrict__ s, uint32_t* __rest
     }
 }
 
+// uncompressed bytes -> wire point at w.  false: malformed (flags / prefix, a coordinate >= p, not on the curve) -- w then
+// holds infinity.  Membership of the prime-order subgroup is k_records_subgroup's business, as for version 1.
+template <class C>
+__device__ bool point_uncompressed_read(const uint8_t* __restrict__ s, uint32_t* __restrict__ w) {
+    using P = typename C::Fp;
+    constexpr int N = P::N;
+    auto fail_point = [&]() {
+        for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
+        w[2 * N] = 1;
+        return false;
+    };
+    if constexpr (C::ID == 2) {
+        return fail_point();
+    } else {
+        constexpr int FB = N * 4;                       // bytes per coordinate
+        constexpr int OFF = C::ID == 0 ? 0 : 1;         // SEC1 prefix byte
+        uint32_t x[N], y[N];
+        for (int t = 0; t < N; t++) x[t] = y[t] = 0;
+        bool inf = false;
+        if (C::ID == 0) {
+            const uint8_t f = s[0];
+            if (f & 0xA0) return fail_point();          // compressed form / sign bit have no place here
+            inf = (f & 0x40) != 0;
+        } else {
+            bool all_zero = true;
+            for (int b = 0; b < 65; b++) all_zero = all_zero && s[b] == 0;
+            inf = all_zero;
+            if (!inf && s[0] != 0x04) return fail_point();
+        }
+        for (int b = 0; b < FB; b++) {
+            const int k = FB - 1 - b;
+            const uint32_t vx = (C::ID == 0 && b == 0) ? (uint32_t)(s[0] & 0x1f) : (uint32_t)s[OFF + b];
+            x[k >> 2] |= vx << (8 * (k & 3));
+            y[k >> 2] |= (uint32_t)s[OFF + FB + b] << (8 * (k & 3));
+        }
+        if (inf) {
+            bool zero = true;
+            for (int t = 0; t < N; t++) zero = zero && x[t] == 0 && y[t] == 0;
+            if (!zero) return fail_point();             // infinity is 0x40 00 .. 00 / 65 zero bytes
+            for (int t = 0; t < 2 * N + 2; t++) w[t] = 0;
+            w[2 * N] = 1;
+            return true;
+        }
+        for (int t = 0; t < N; t++) {
+            w[t] = x[t];
+            w[N + t] = y[t];
+        }
+        w[2 * N] = 0;
+        w[2 * N + 1] = 0;
+        Aff<C> a;
+        if (!aff_from_wire<C>(w, a)) return fail_point();   // coordinates < p, on the curve
+        return true;
+    }
+}
+
 // one thread per point: compressed bytes -> wire; ok[i] = 0 valid, 1 malformed (see point_decompress)
 template <class C>
 __global__ void __launch_bounds__(64, 2) k_points_decompress(const uint8_t* __restrict__ in, uint32_t* __restrict__ wire,
@@ -223,8 +291,8 @@ __global__ void __launch_bounds__(64, 2) k_points_decompress(const uint8_t* __re
 // ---- the proof container on the device (layout: include/bpp_amd.h "serialized proofs") ---------------------------
 constexpr uint32_t CONTAINER_HDR = 12;   // "BPP+" | version | curve | n | m | k | 3 reserved zero bytes
 template <class C>
-__host__ __device__ constexpr size_t container_bytes(uint32_t k) {
-    return CONTAINER_HDR + (size_t)(3 + 2 * k) * compressed_bytes<C>() + 96;
+__host__ __device__ constexpr size_t container_bytes(uint32_t k, uint32_t version = 1) {
+    return CONTAINER_HDR + (size_t)(3 + 2 * k) * container_point_bytes<C>(version) + 96;
 }
 
 // One lane per point of every proof's verification record [A, wip.A, wip.B, L.., R.., V_0..V_{m-1}]: the 3 + 2k points
@@ -235,21 +303,22 @@ template <class C>
 __global__ void __launch_bounds__(64, 2) k_container_decode(VerifyShape s, const uint8_t* __restrict__ proofs,
                                                          const uint8_t* __restrict__ commitments,
                                                          uint32_t* __restrict__ records, uint32_t* __restrict__ scalars,
-                                                         uint32_t* __restrict__ status, size_t count) {
+                                                         uint32_t* __restrict__ status, size_t count, uint32_t version) {
     constexpr int N = C::Fp::N;
-    constexpr int CB = compressed_bytes<C>();
+    const int CB = container_point_bytes<C>(version);   // version 2: uncompressed points (and commitments)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count * s.NV) return;
     const size_t p = i / s.NV;
     const uint32_t t = (uint32_t)(i - p * s.NV);
     const uint32_t npp = 3 + 2 * s.k;
-    const uint8_t* rec = proofs + p * container_bytes<C>(s.k);
+    const uint8_t* rec = proofs + p * container_bytes<C>(s.k, version);
     const uint8_t* src = t < npp ? rec + CONTAINER_HDR + (size_t)t * CB : commitments + (p * s.m + (t - npp)) * CB;
     // the G1 membership test is a kernel of its own (k_records_subgroup below): two chains of 64 doublings beside the
     // square root's window table in one kernel cost 256 VGPRs and scratch
-    bool good = point_decompress<C, false>(src, records + i * (2 * N + 2));
+    bool good = version == 2 ? point_uncompressed_read<C>(src, records + i * (2 * N + 2))
+                             : point_decompress<C, false>(src, records + i * (2 * N + 2));
     if (t == 0) {
-        const uint8_t hdr[CONTAINER_HDR] = {'B', 'P', 'P', '+', 1, (uint8_t)C::ID, (uint8_t)s.n, (uint8_t)s.m, (uint8_t)s.k, 0, 0, 0};
+        const uint8_t hdr[CONTAINER_HDR] = {'B', 'P', 'P', '+', (uint8_t)version, (uint8_t)C::ID, (uint8_t)s.n, (uint8_t)s.m, (uint8_t)s.k, 0, 0, 0};
         for (uint32_t b = 0; b < CONTAINER_HDR; b++) good = good && rec[b] == hdr[b];
         const uint8_t* sc = rec + CONTAINER_HDR + (size_t)npp * CB;
         for (int e = 0; e < 3; e++) {

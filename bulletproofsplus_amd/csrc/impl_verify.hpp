@@ -149,7 +149,8 @@ struct VerifyImpl {
     // d_proofs: count x container_bytes ; d_commitments: count x m compressed points ; d_ok: 0 Ok / 1 VerificationError /
     // 2 FormatError per proof.  Everything on `st`, no host synchronisation.
     static int run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
-                              bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes, hipStream_t st);
+                              bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes, hipStream_t st,
+                              uint32_t version = 1);
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
@@ -461,9 +462,11 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
 template <class C>
 int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
                                   bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
-                                  hipStream_t st) {
+                                  hipStream_t st, uint32_t version) {
     const VerifyShape& s = v->s;
     if (s.n > 255 || s.m > 255) return fail(BPP_E_ARG, "the container holds n, m <= 255");
+    if (version != 1 && !(version == 2 && uncompressed_bytes<C>() != 0))
+        return fail(BPP_E_ARG, "container version 2 (uncompressed points) is not offered for this curve");
     const SerLayout L = ser_layout(s, count);
     if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
     uint8_t* ws = static_cast<uint8_t*>(d_workspace);
@@ -473,7 +476,7 @@ int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, cons
     uint64_t* w_ch = reinterpret_cast<uint64_t*>(ws + L.challenges);
     HIPCHK(zero_words_async(w_st, count * 4, st));
     hipLaunchKernelGGL(k_container_decode<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, s, d_proofs, d_commitments,
-                       w_rec, w_sc, w_st, count);
+                       w_rec, w_sc, w_st, count, version);
     if constexpr (C::ID == 0)   // cofactor > 1: membership of the prime-order subgroup
         hipLaunchKernelGGL(k_records_subgroup<C>, dim3(cdiv(count * s.NV, 64)), dim3(64), 0, st, w_rec, w_st, s.NV,
                            count * s.NV);

@@ -1121,12 +1121,50 @@ class Ristretto255:
 CURVE_IDS = {"bls12_381": 0, "secp256k1": 1, "ed25519": 2}
 
 
-def encode_proof(curve: dict, n: int, m: int, proof) -> bytes:
+def uncompressed_point(curve: dict, P) -> bytes:
+    """container version 2: BLS12-381 G1 96 bytes x | y big-endian (byte 0 bit 6 = infinity), secp256k1 SEC1 04 | x | y
+    (infinity = 65 zero bytes)"""
+    if curve["name"] == "bls12_381":
+        if P is None:
+            return bytes([0x40]) + bytes(95)
+        return P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big")
+    if curve["name"] == "secp256k1":
+        if P is None:
+            return bytes(65)
+        return b"\x04" + P[0].to_bytes(32, "big") + P[1].to_bytes(32, "big")
+    raise ValueError("no uncompressed encoding for " + curve["name"])
+
+
+def parse_uncompressed_point(curve: dict, data: bytes):
+    """-> (ok, point): ok False for a malformed encoding (flags / prefix, a coordinate >= p, not on the curve)"""
+    p, b = curve["p"], curve["b"]
+    if curve["name"] == "bls12_381":
+        assert len(data) == 96
+        f = data[0]
+        if f & 0xA0:
+            return False, None
+        x = int.from_bytes(bytes([f & 0x1F]) + data[1:48], "big")
+        y = int.from_bytes(data[48:], "big")
+        if f & 0x40:
+            return (x == 0 and y == 0), None
+    else:
+        assert len(data) == 65
+        if data == bytes(65):
+            return True, None
+        if data[0] != 4:
+            return False, None
+        x, y = int.from_bytes(data[1:33], "big"), int.from_bytes(data[33:], "big")
+    if x >= p or y >= p or (x == 0 and y == 0) or (y * y - x * x * x - b) % p:
+        return False, None
+    return True, (x, y)
+
+
+def encode_proof(curve: dict, n: int, m: int, proof, version: int = 1) -> bytes:
     w = proof.proof
     k = len(w.L_vec)
-    out = b"BPP+" + bytes([1, CURVE_IDS[curve["name"]], n, m, k, 0, 0, 0])
+    out = b"BPP+" + bytes([version, CURVE_IDS[curve["name"]], n, m, k, 0, 0, 0])
     for P in [proof.A, w.A, w.B] + list(w.L_vec) + list(w.R_vec):
-        out += compress_point(curve, P)
+        out += compress_point(curve, P) if version == 1 else uncompressed_point(curve, P)
     for x in (w.r_prime, w.s_prime, w.d_prime):
         out += int(x).to_bytes(32, "little")
     return out
@@ -1139,18 +1177,19 @@ def point_in_prime_subgroup(curve: dict, G, P) -> bool:
     return G.is_zero(G.mul(P, curve["r"]))
 
 
-def decode_proof(curve: dict, G, n: int, m: int, data: bytes):
+def decode_proof(curve: dict, G, n: int, m: int, data: bytes, version: int = 1):
     """-> RangeProof, or None for ProofError::FormatError"""
     mn = n * m
     k = mn.bit_length() - 1
-    cb = {"bls12_381": 48, "secp256k1": 33, "ed25519": 32}[curve["name"]]
+    cb = ({"bls12_381": 48, "secp256k1": 33, "ed25519": 32} if version == 1 else {"bls12_381": 96, "secp256k1": 65})[curve["name"]]
     if len(data) != 12 + (3 + 2 * k) * cb + 96:
         return None
-    if data[:12] != b"BPP+" + bytes([1, CURVE_IDS[curve["name"]], n, m, k, 0, 0, 0]):
+    if data[:12] != b"BPP+" + bytes([version, CURVE_IDS[curve["name"]], n, m, k, 0, 0, 0]):
         return None
     pts = []
     for i in range(3 + 2 * k):
-        ok, P = decompress_point(curve, data[12 + i * cb: 12 + (i + 1) * cb])
+        chunk = data[12 + i * cb: 12 + (i + 1) * cb]
+        ok, P = decompress_point(curve, chunk) if version == 1 else parse_uncompressed_point(curve, chunk)
         if not ok or not point_in_prime_subgroup(curve, G, P):
             return None
         pts.append(P)

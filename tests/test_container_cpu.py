@@ -101,3 +101,42 @@ def test_container_round_trip_and_rejections():
     blob = bytearray(P.encode_proof(c, 4, 2, proof))
     blob[12:60] = P.compress_point(c, (0, 2))
     assert P.decode_proof(c, G, 4, 2, bytes(blob)) is None
+
+
+def test_container_version_2_uncompressed_points():
+    """container version 2 (uncompressed points; include/bpp_amd.h): round trip, and every rejection of version 1 plus the
+    ones of the point form -- compressed flag set, a coordinate >= p, a point off the curve, a point outside G1"""
+    for cname, ub in (("secp256k1", 65), ("bls12_381", 96)):
+        c = P.CURVES[cname]
+        G = P.make_group(cname, False)
+        n, vals = 4, [9, 3]
+        pk, prover, proof = P.prove_case(cname, n, vals, [5, 6], shadow=False)
+        blob = P.encode_proof(c, n, 2, proof, version=2)
+        k = 3
+        assert len(blob) == 12 + (3 + 2 * k) * ub + 96 and blob[4] == 2
+        back = P.decode_proof(c, G, n, 2, blob, version=2)
+        assert back is not None and back.verify(pk, n, prover.commitment_vec)
+        assert back.A == proof.A and back.proof.L_vec == proof.proof.L_vec and back.proof.R_vec == proof.proof.R_vec
+        assert P.decode_proof(c, G, n, 2, blob, version=1) is None                      # a version 2 blob is not version 1
+        assert P.decode_proof(c, G, n, 2, P.encode_proof(c, n, 2, proof), version=2) is None
+        bad = bytearray(blob)
+        bad[12 + ub - 1] ^= 1                                                            # y of A off by one: not on the curve
+        assert P.decode_proof(c, G, n, 2, bytes(bad), version=2) is None
+        bad = bytearray(blob)
+        bad[12] = 0x80 | bad[12] if cname == "bls12_381" else 0x02                        # compressed flag / prefix
+        assert P.decode_proof(c, G, n, 2, bytes(bad), version=2) is None
+        bad = bytearray(blob)
+        off = 12 if cname == "bls12_381" else 13
+        bad[off:off + (48 if cname == "bls12_381" else 32)] = (c["p"]).to_bytes(48 if cname == "bls12_381" else 32, "big")   # x = p
+        assert P.decode_proof(c, G, n, 2, bytes(bad), version=2) is None
+        bad = bytearray(blob)
+        bad[-32:] = (c["r"]).to_bytes(32, "little")
+        assert P.decode_proof(c, G, n, 2, bytes(bad), version=2) is None
+        inf = P.uncompressed_point(c, None)
+        assert P.parse_uncompressed_point(c, inf) == (True, None)
+    c = P.BLS12_381
+    G = P.make_group("bls12_381", False)
+    pk, prover, proof = P.prove_case("bls12_381", 4, [9, 3], [5, 6], shadow=False)
+    blob = bytearray(P.encode_proof(c, 4, 2, proof, version=2))
+    blob[12:108] = P.uncompressed_point(c, (0, 2))                                       # order 3: on the curve, outside G1
+    assert P.decode_proof(c, G, 4, 2, bytes(blob), version=2) is None

@@ -233,3 +233,74 @@ def test_serialized_device_path(cname):
         with pytest.raises(B.BppError):
             bv.verify_serialized_device(d_pr.data_ptr(), d_cm.data_ptr(), cnt, d_ok.data_ptr(), d_ws.data_ptr(), wsb - 1)
     bv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("secp256k1", 1)])
+def test_container_version_2_on_device(cname, cid):
+    """Container version 2 (uncompressed points): the engine's encoder == the restatement's, the device decode + verify gives
+    the statuses of the restatement for valid proofs and for every kind of rejection, in both challenge modes; the same
+    proofs through version 1 give the same verdicts."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    c = P.CURVES[cname]
+    G = P.make_group(cname, False)
+    n, m, cnt = 4, 2, 9
+    a = B.Arith.init(cname)
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=4)
+    vals = [[(5 * i + 1) % 16, (3 * i) % 16] for i in range(cnt)]
+    gams = [[i + 1, 2 * i + 5] for i in range(cnt)]
+    ub = B.uncompressed_bytes(a)
+    assert ub == {"bls12_381": 96, "secp256k1": 65}[cname]
+    dev = torch.device("cuda:0")
+    for fs in (False, True):
+        pts, scs, V = bv.prove_batch(vals, gams, transcript=fs)
+        blobs = B.encode_proofs(a, n, m, pts, scs, version=2)
+        assert blobs.shape == (cnt, B.proof_bytes(a, n, m, 2)) and B.proof_bytes(a, n, m, 2) == 12 + 9 * ub + 96
+        comm = B.uncompressed_points(a, V.reshape(-1, a.PW)).reshape(cnt, m, ub)
+        if not fs:
+            for i in range(3):
+                _, prover, proof = P.prove_case(cname, n, vals[i], gams[i], shadow=False)
+                assert bytes(blobs[i]) == P.encode_proof(c, n, m, proof, version=2)
+                assert bytes(comm[i, 0]) == P.uncompressed_point(c, prover.commitment_vec[0])
+        assert bv.verify_serialized(blobs, comm, transcript=fs, uncompressed=True).tolist() == [0] * cnt
+        # version 1 of the same proofs: the same verdicts
+        b1 = B.encode_proofs(a, n, m, pts, scs)
+        c1 = B.compress_points(a, V.reshape(-1, a.PW)).reshape(cnt, m, -1)
+        assert bv.verify_serialized(b1, c1, transcript=fs).tolist() == [0] * cnt
+        bad = blobs.copy()
+        exp = [0] * cnt
+        bad[0, 4] = 1                                   # version byte says 1
+        exp[0] = 2
+        bad[1, 12 + ub - 1] ^= 1                        # y of A off by one: off the curve
+        exp[1] = 2
+        bad[2, 12 + ub] = (bad[2, 12 + ub] | 0x80) if cname == "bls12_381" else 0x02   # wip.A: compressed flag / prefix
+        exp[2] = 2
+        bad[3, -96] ^= 1                                # r' off by one: parses, fails the MulVec
+        exp[3] = 1
+        bad[4, -32:] = np.frombuffer(c["r"].to_bytes(32, "little"), dtype=np.uint8)      # delta' = r
+        exp[4] = 2
+        if cname == "bls12_381":
+            bad[5, 12:12 + ub] = np.frombuffer(P.uncompressed_point(c, (0, 2)), dtype=np.uint8)   # outside G1
+            exp[5] = 2
+        cbad = comm.copy()
+        cbad[6, 1, -1] ^= 1                             # a commitment off the curve
+        exp[6] = 2
+        for i in range(cnt):
+            dec = P.decode_proof(c, G, n, m, bytes(bad[i]), version=2)
+            assert (dec is None) == (exp[i] == 2 and i != 6), i
+        assert bv.verify_serialized(bad, cbad, transcript=fs, uncompressed=True).tolist() == exp
+        d_pr = torch.from_numpy(bad).to(dev)
+        d_cm = torch.from_numpy(cbad).to(dev)
+        d_ok = torch.full((cnt,), 9, dtype=torch.int32, device=dev)
+        wsb = bv.serialized_workspace_bytes(cnt)
+        d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        bv.verify_serialized_device(d_pr.data_ptr(), d_cm.data_ptr(), cnt, d_ok.data_ptr(), d_ws.data_ptr(), wsb, transcript=fs,
+                                    uncompressed=True)
+        torch.cuda.synchronize()
+        assert d_ok.cpu().numpy().tolist() == exp
+    # not offered for ristretto255
+    a_e = B.Arith.init("ed25519")
+    assert B.uncompressed_bytes(a_e) == 0 and B.proof_bytes(a_e, n, m, 2) == 0
+    bv.close()
