@@ -27,8 +27,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
 The oracle is used only for that leg.  Beside `value` (never as it) the line also carries separately timed legs:
 "tamper_check" (exact verdict vector of the bench batch with K tampered proofs), "latency" (B = 1 / 16 / 256),
 "prove" (batched device prover, device-resident), "serialized" (the same batch as proof containers + compressed
-commitments: decode with subgroup check + verify), "combined_check", "c3" (4096 x (64,1)), "hard_distribution",
-"other_curves".
+commitments: decode with subgroup check + verify; and as version-2 containers with uncompressed points),
+"combined_check", "c3" (4096 x (64,1)), "hard_distribution", "other_curves" (secp256k1, edwards25519: the metric's shape,
+the C3 shape and one proof alone), "production" (hashed generators + Fiat-Shamir transcript + blinding from a key +
+serialized input, with the stage split), "single_call" (RangeProof::prove / verify through the literal host-pointer API,
+ms per call), "msm" (MulVec::calculate as a device-resident seam: N = 2^16..2^22 points on the three curves, with
+`roofline` and `alu` per point), "sustained" (--sustained-steps) and, for world > 1, "comm_ms" (the exchange step).
+Every leg ends with an untimed exact-verdict check on a tampered subset and carries a `roofline` block.
 """
 
 import argparse

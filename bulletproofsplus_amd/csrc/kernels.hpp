@@ -224,6 +224,41 @@ __device__ __forceinline__ Jac<C> jac_dbl_tri(const Jac<C>& p) {
     return r;
 }
 
+// The same idea for the Edwards instantiation, FOUR lanes per doubling (lanes 4g..4g+3 hold the same extended point; every
+// lane of the wave calls this): dbl-2008-hwcd is 4S then 4M with nothing but additions between them, so four lanes finish
+// in two product-times instead of eight:  X^2 | Y^2 | Z^2 | (X+Y)^2 ,  then  E F | G H | E H | F G.  72 words travel by
+// ds_bpermute per doubling.  edwards25519 has no endomorphism, so its tails are twice as long as the other curves'
+// (~250 doublings): this is what shortens them.
+__device__ __forceinline__ Jac<Ed25519> ed_dbl_quad(const Jac<Ed25519>& p) {
+    using F = ed::F;
+    const int lane = threadIdx.x & 63;
+    const int role = lane & 3, g0 = lane - role;
+    const F s1 = fe_sqr(ed::select(role == 0, p.X, ed::select(role == 1, p.Y, ed::select(role == 2, p.Z, fe_add(p.X, p.Y)))));
+    const F A = wave_shfl(s1, g0), B = wave_shfl(s1, g0 + 1), Zs = wave_shfl(s1, g0 + 2), XY = wave_shfl(s1, g0 + 3);
+    const F C = fe_dbl(Zs), D = fe_neg(A);
+    const F E = fe_sub(fe_sub(XY, A), B), G = fe_add(D, B), Fq = fe_sub(G, C), H = fe_sub(D, B);
+    const F m2 = fe_mul(ed::select((role & 1) == 0, E, ed::select(role == 1, G, Fq)),
+                        ed::select(role == 0, Fq, ed::select(role == 3, G, H)));   // E F | G H | E H | F G
+    Jac<Ed25519> r;
+    r.X = wave_shfl(m2, g0);
+    r.Y = wave_shfl(m2, g0 + 1);
+    r.T = wave_shfl(m2, g0 + 2);
+    r.Z = wave_shfl(m2, g0 + 3);
+    return r;
+}
+// lanes per shared doubling of a curve, and the shared doubling itself
+template <class C>
+constexpr uint32_t dbl_lanes() {
+    return C::ID == 2 ? 4u : 3u;
+}
+template <class C>
+__device__ __forceinline__ Jac<C> jac_dbl_shared(const Jac<C>& p) {
+    if constexpr (C::ID == 2)
+        return ed_dbl_quad(p);
+    else
+        return jac_dbl_tri<C>(p);
+}
+
 // ---- wire <-> device images --------------------------------------------------------------------------
 
 // wire points -> affm.  per_group > 0: bad[i / per_group] is set when point i is invalid (coordinate
@@ -903,6 +938,36 @@ __device__ __forceinline__ void var_horner_wave2(const uint32_t* __restrict__ ws
     if (wave == 0 && lane == 0) jac_stg<C>(out + b * JW, jac_add(R, jac_load<C>(lds)));
 }
 
+// The wave-per-proof form for the 65 windows of the Edwards instantiation: sixteen lane-quads, quad q runs Horner's rule
+// over windows q, q + 16, q + 32, q + 48 (64 doublings between them; quad 0 also takes window 64 on top), then 4 q more
+// doublings, every doubling shared by the quad's four lanes (ed_dbl_quad) -- at most 256 doublings of two product-times
+// each on the critical path instead of 256 of eight -- and a butterfly adds the sixteen quads.  One wave.
+__device__ __forceinline__ void var_horner_wave_ed(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
+                                                   uint32_t groups) {
+    using C = Ed25519;
+    constexpr uint32_t NW = var_windows<C>();   // 65
+    static_assert(NW == 65, "sixteen quads x four windows + one");
+    constexpr int JW = jac_words<C>();
+    const uint32_t lane = threadIdx.x & 63u, q = lane >> 2;
+    Jac<C> acc = jac_inf<C>();
+    if (q == 0) {   // (a quad only ever reads its own four lanes, so quads may diverge from one another)
+        acc = var_wsum_ld<C, true>(wsum, b, 64, groups);
+        for (int t = 0; t < 64; t++) acc = ed_dbl_quad(acc);
+    }
+    for (int w = 3; w >= 0; w--) {
+        acc = jac_add(acc, var_wsum_ld<C, true>(wsum, b, q + 16 * (uint32_t)w, groups));
+        const int times = w > 0 ? 64 : 60;   // after the last window: 4 q doublings, the wave runs the maximum (60)
+        for (int t = 0; t < times; t++) {
+            const Jac<C> d = ed_dbl_quad(acc);
+            if (w > 0 || (uint32_t)t < 4 * q) acc = d;
+        }
+    }
+    acc = wave_shfl(acc, (int)((4 * lane) & 63u));   // quad q's sum to lane q
+    if (lane >= 16) acc = jac_inf<C>();
+    acc = wave_sum_jac<C>(acc, 16);
+    if (lane == 0) jac_stg<C>(out + b * JW, acc);
+}
+
 // Between the two: EIGHT lanes per proof (eight proofs per wave), for batches that are too large for a wave per proof
 // but whose fixed-generator work is over before a one-lane chain would be (4 096 proofs of (64,1): the chain of 128
 // doublings + 33 additions was 2.2 of the pass's 3.7 ms).  Lane g runs Horner over its own eighth of the windows, then
@@ -1034,8 +1099,8 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
             const size_t b = blockIdx.x;
             if constexpr (var_glv<C>()) {   // 33 windows: both waves, three lanes per window (var_horner_wave2)
                 if (b < horner_count) var_horner_wave2<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
-            } else {
-                if (b < horner_count && threadIdx.x < 64) var_horner_wave<C>(wsum, var_out, b, lds, horner_tree == 3 ? VAR_GROUPS : 1u);
+            } else {   // 65 windows (edwards25519): one wave, a lane-quad per four windows (var_horner_wave_ed)
+                if (b < horner_count && threadIdx.x < 64) var_horner_wave_ed(wsum, var_out, b, horner_tree == 3 ? VAR_GROUPS : 1u);
             }
         } else {             // one lane per proof
             const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -41,8 +41,9 @@
 //                  sum_l l * run_l, a butterfly reduces the rest.  Out: (A_t, T_t) per tile.
 //   k_pip_windows  per window: R_j = sum_t A_t + (64 S) sum_t t T_t  (lane-local double-and-add by the tile number,
 //                  wave butterfly)
-//   k_pip_final    lane j doubles R_j off(j) times (all windows at once: the critical path is the top window's
-//                  off(W-1) doublings and log2 W additions of a shuffle butterfly), then the affine wire point
+//   k_pip_final    window j doubles R_j off(j) times, all windows at once, 3 / 4 lanes sharing every doubling (the
+//                  critical path is the top window's off(W-1) doublings and log2 W additions of a butterfly), then the
+//                  affine wire point
 #pragma once
 #include <algorithm>
 
@@ -736,60 +737,55 @@ __global__ void __launch_bounds__(64) k_pip_windows(PipShape s, const uint32_t* 
     if (lane == 0) jac_stg<C>(window_sums + (size_t)j * JW, R);
 }
 
-// sum_j 2^off(j) R_j: lane j doubles its window sum off(j) times -- every window at once, so the critical path is the top
-// window's off(W-1) doublings -- and a shuffle butterfly adds the lanes (log2 W additions).  More than 64 windows (an
-// explicit narrow width): lane l takes windows l, l + 64, .. by Horner's rule over its own first.  The result goes to
-// out_jac (may be null) and, as the affine wire point, to out_wire (may be null).
+// sum_j 2^off(j) R_j.  A block of two waves; window j doubles its sum off(j) times, all windows at once, and every
+// doubling is shared by the 3 (Weierstrass: jac_dbl_tri) or 4 (Edwards: ed_dbl_quad) lanes the window has been given
+// (kernels.hpp) -- the critical path is the top window's off(W-1) doublings at three / two product-times each -- then the
+// windows' lanes are compacted, a butterfly adds them and the second wave's sum joins through LDS.  More windows than the
+// two waves hold (an explicit narrow width): one lane per window, windows lane, lane + 64, .. by Horner's rule.  The result
+// goes to out_jac (may be null) and, as the affine wire point, to out_wire (may be null).
 template <class C>
-__global__ void __launch_bounds__(64) k_pip_final(PipShape s, const uint32_t* __restrict__ window_sums,
-                                                  uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_wire) {
+__global__ void __launch_bounds__(128) k_pip_final(PipShape s, const uint32_t* __restrict__ window_sums,
+                                                   uint32_t* __restrict__ out_jac, uint32_t* __restrict__ out_wire) {
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
+    constexpr uint32_t LPW = dbl_lanes<C>(), PER = 64 / LPW;   // lanes per window, windows per wave
+    __shared__ __align__(16) uint32_t lds[JW];
     if (blockIdx.x != 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    if constexpr (C::ID != 2) {
-        if (3 * s.W <= 64) {
-            // few windows (the usual case: W = 8..20): THREE lanes per window share every doubling (jac_dbl_tri,
-            // kernels.hpp: three levels of one field product each instead of seven products in a row), then the windows'
-            // lanes are compacted and summed by the butterfly
-            const uint32_t j = lane / 3;
-            Jac<C> R = j < s.W ? jac_ldg<C>(window_sums + (size_t)j * JW) : jac_inf<C>();
-            const uint32_t times = j < s.W ? s.off(j) : 0u, maxt = s.off(s.W - 1);
-            for (uint32_t t = 0; t < maxt; t++) {
-                const Jac<C> d = jac_dbl_tri<C>(R);
-                if (t < times) R = d;
-            }
-            R = wave_shfl(R, (int)((3 * lane) & 63u));
-            if (lane >= s.W) R = jac_inf<C>();
-            uint32_t span = 1;
-            while (span < s.W) span <<= 1;
-            R = wave_sum_jac<C>(R, (int)span);
-            if (lane != 0) return;
-            if (out_jac) jac_stg<C>(out_jac, R);
-            if (out_wire) {
-                uint32_t w[2 * N + 2];
-                aff_to_wire(jac_to_aff(R), w);
-#pragma unroll
-                for (int t = 0; t < 2 * N + 2; t++) out_wire[t] = w[t];
-            }
-            return;
-        }
-    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     Jac<C> acc = jac_inf<C>();
-    uint32_t at = 0;   // acc is in units of 2^at
-    for (uint32_t hi = ((s.W - 1 - lane) / 64) * 64 + lane; lane < s.W; hi -= 64) {   // windows lane + 64 i, highest first
+    if (s.W <= 2 * PER) {
+        const uint32_t q = lane / LPW, j = wave * PER + q;
+        const bool has = q < PER && j < s.W;
+        acc = has ? jac_ldg<C>(window_sums + (size_t)j * JW) : jac_inf<C>();
+        const uint32_t times = has ? s.off(j) : 0u;
+        const uint32_t last = min(s.W, (wave + 1) * PER);                   // one past this wave's top window
+        const uint32_t maxt = last > wave * PER ? s.off(last - 1) : 0u;     // wave-uniform
+        for (uint32_t t = 0; t < maxt; t++) {
+            const Jac<C> d = jac_dbl_shared<C>(acc);
+            if (t < times) acc = d;
+        }
+        acc = wave_shfl(acc, (int)((LPW * lane) & 63u));
+        if (lane >= PER || wave * PER + lane >= s.W) acc = jac_inf<C>();
+        acc = wave_sum_jac<C>(acc, 32);
+        if (wave == 1 && lane == 0) jac_store(acc, lds);
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        acc = jac_add(acc, jac_load<C>(lds));
+    } else {
+        if (wave != 0) return;
+        uint32_t at = 0;   // acc is in units of 2^at
+        for (uint32_t hi = ((s.W - 1 - lane) / 64) * 64 + lane; lane < s.W; hi -= 64) {   // windows lane + 64 i, highest first
+            if (!acc.is_inf())
+                for (uint32_t t = s.off(hi); t < at; t++) acc = jac_dbl(acc);
+            at = s.off(hi);
+            acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)hi * JW));
+            if (hi < 64) break;
+        }
         if (!acc.is_inf())
-            for (uint32_t t = s.off(hi); t < at; t++) acc = jac_dbl(acc);
-        at = s.off(hi);
-        acc = jac_add(acc, jac_ldg<C>(window_sums + (size_t)hi * JW));
-        if (hi < 64) break;
+            for (uint32_t t = 0; t < at; t++) acc = jac_dbl(acc);
+        acc = wave_sum_jac<C>(acc, 64);
+        if (lane != 0) return;
     }
-    if (!acc.is_inf())
-        for (uint32_t t = 0; t < at; t++) acc = jac_dbl(acc);
-    uint32_t span = 1;
-    while (span < s.W && span < 64) span <<= 1;
-    acc = wave_sum_jac<C>(acc, (int)span);
-    if (lane != 0) return;
     if (out_jac) jac_stg<C>(out_jac, acc);
     if (out_wire) {
         uint32_t w[2 * N + 2];
@@ -914,7 +910,7 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     hipLaunchKernelGGL(k_pip_tiles<C>, dim3(s.ntiles), dim3(64), 0, st, s, buckets, tiles);
     hipLaunchKernelGGL(k_pip_windows<C>, dim3(s.W), dim3(64), 0, st, s, tiles, wsums);
     mark(4);
-    hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(64), 0, st, s, wsums, (uint32_t*)nullptr, d_out_wire);
+    hipLaunchKernelGGL(k_pip_final<C>, dim3(1), dim3(128), 0, st, s, wsums, (uint32_t*)nullptr, d_out_wire);
     mark(5);
     return hipGetLastError();
 }
