@@ -1162,6 +1162,38 @@ def main():
                 del d_ws_m, d_sc_m, d_pt_m
                 torch.cuda.empty_cache()
             msm["curves"][mc] = rows
+        # the reference's MulVec::calculate is one scalar multiplication per term on one thread (mulvec.rs:28-31): the CPU
+        # oracle's restatement of exactly that, timed on a bounded sample of the same kind of input
+        if args.cpu_seconds > 0 and world == 1:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle as O_
+                a_c = B.Arith.init("bls12_381", local_rank)
+                g_c = B.PublicKey.new(a_c, 0).gh[0]
+                ns = 512
+                rng = np.random.RandomState(7)
+                kw = np.zeros((ns, 4), dtype=np.uint64)
+                kw[:, 0] = rng.randint(1, 2**62, size=ns).astype(np.uint64)
+                pts_c = a_c.scalar_mul(kw, np.broadcast_to(g_c, (ns, a_c.PW)).copy())
+                sc_c = rng.randint(0, 2**63 - 1, size=(ns, 4)).astype(np.uint64)
+                sc_c[:, 3] >>= np.uint64(4)
+                t0 = time.perf_counter()
+                res_c = O_.msm(0, sc_c, pts_c)
+                dt_c = time.perf_counter() - t0
+                d_o = torch.zeros(a_c.PW, dtype=torch.int64, device=dev)
+                wsb_c = B.msm_workspace_bytes(a_c, ns, 0)
+                d_w = torch.empty(wsb_c, dtype=torch.uint8, device=dev)
+                d_sc_c = torch.from_numpy(sc_c.view(np.int64)).to(dev)
+                d_pt_c = torch.from_numpy(pts_c.view(np.int64)).to(dev)
+                B.msm_device(a_c, d_sc_c.data_ptr(), d_pt_c.data_ptr(), ns, d_o.data_ptr(), d_w.data_ptr(), wsb_c, stream=stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_o.cpu().numpy().view(np.uint64), res_c), "msm leg: device MulVec differs from the oracle's on the CPU sample"
+                msm["cpu_baseline"] = {"value": ns / dt_c, "unit": "points/s", "cores": 1, "kind": "port",
+                                       "sample": "one naive MulVec of %d full-width terms on BLS12-381 by the CPU oracle (reference semantics, "
+                                                 "mulvec.rs:20-33; the reference is single-threaded), %.2f s wall; the device result of the same "
+                                                 "input is bit-identical" % (ns, dt_c)}
+            except Exception as e:   # the oracle is optional test infrastructure: the leg stands without it
+                msm["cpu_baseline"] = {"error": str(e)[:200]}
         msm["value"] = msm["curves"]["bls12_381"][-1]["value"]
         msm["note"] = ("value = the largest BLS12-381 point; roofline.achieved = N x (affine point + scalar) bytes / the summed stage "
                        "time of one call (HIP events on the launch stream) -- integer-ALU bound like the verifier; alu = bucket additions "

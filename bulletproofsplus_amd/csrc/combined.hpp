@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(64) k_comb_sum_partials(const uint32_t* __rest
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t lane_zero;  // keeps the wave-uniform chain on the vector unit (see k_pip_final)
+    uint32_t lane_zero;  // keeps the wave-uniform chain on the vector unit (a uniform address would move the arithmetic to the scalar unit)
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
     partials += lane_zero;
     Jac<C> acc = jac_inf<C>();

@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(64, BPP_VAR_TABLES_WAVES) k_tbl_fill(VerifySha
 // out[b] = sum_j 16^j * wsum[b][j] by Horner's rule -- 256 doublings that can only run one after the other.
 // Alone on the chip this is 128 waves of pure latency, so it does not get a launch of its own: the first
 // `horner_blocks` blocks of k_fixed_msm's grid run it, beside the blocks that do the fixed-generator sums
-// (one lane per proof; for small batches one wave per proof: var_horner_wave).
+// (one lane per proof; for small batches a block per proof: var_horner_wave2 / var_horner_wave_ed).
 // window sum j of proof b.  SPLIT (the layout k_var_windows writes for the tree Horner): S_j = (half 0) + (half 1)
 template <class C, bool SPLIT>
 __device__ __forceinline__ Jac<C> var_wsum_ld(const uint32_t* __restrict__ wsum, size_t b, uint32_t j, uint32_t groups = 1) {
@@ -868,46 +868,6 @@ __device__ __forceinline__ void var_horner_lane(const uint32_t* __restrict__ wsu
         acc = jac_add(acc, var_wsum_ld<C, false>(wsum, b, (uint32_t)j));
     }
     jac_stg<C>(out + b * JW, acc);
-}
-
-// The same sum by one WAVE per proof, for small batches: a binary tree over the windows.  Lane j starts with S_j;
-// at level l the lanes whose index is a multiple of 2^(l+1) take the partial of lane j + 2^l (through LDS), double
-// it 4 * 2^l times and add it.  The 256 doublings still form one chain (the top window's path), but the 64
-// additions of Horner's rule shrink to 7 on the critical path: ~2.4 ms instead of 3.5 ms.  `lds_wave`: 64 jacobians.
-template <class C>
-__device__ __forceinline__ void var_horner_wave(const uint32_t* __restrict__ wsum, uint32_t* __restrict__ out, size_t b,
-                                                uint32_t* lds_wave, uint32_t groups) {
-    constexpr uint32_t NW = var_windows<C>(), L = NW - 1;   // L lanes + the carry window
-    static_assert(L == 64 || L == 32, "a power of two of lanes within one wave");
-    constexpr int JW = jac_words<C>();
-    const uint32_t j = threadIdx.x & 63u;
-    Jac<C> acc = j < L ? var_wsum_ld<C, true>(wsum, b, j, groups) : jac_inf<C>();
-    if (j == L - 1) {   // the last window joins the slot before it: S_{L-1} + 16 * S_L
-        Jac<C> t = var_wsum_ld<C, true>(wsum, b, L, groups);
-        if (!t.is_inf()) {
-            t = jac_dbl(t);
-            t = jac_dbl(t);
-            t = jac_dbl(t);
-            t = jac_dbl(t);
-        }
-        acc = jac_add(acc, t);
-    }
-    // the exchange stays inside the wave: LDS serves a wave's accesses in order, so a wavefront-scope fence (for the
-    // compiler) is all the synchronisation it needs -- no block barrier, and an idle second wave can simply leave
-    for (uint32_t stride = 1; stride < L; stride <<= 1) {
-        jac_store(acc, lds_wave + (size_t)j * JW);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if ((j & (2 * stride - 1)) == 0 && j + stride < L) {
-            Jac<C> hi = jac_load<C>(lds_wave + (size_t)(j + stride) * JW);
-            if (!hi.is_inf())
-                for (uint32_t t = 0; t < 4 * stride; t++) hi = jac_dbl(hi);
-            acc = jac_add(acc, hi);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (j == 0) jac_stg<C>(out + b * JW, acc);
 }
 
 // The wave-per-proof form for the curves with 33 windows (GLV), as a BLOCK of two waves: three lanes per window share
