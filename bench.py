@@ -382,6 +382,7 @@ def main():
     t1 = time.perf_counter()
     bv = None
     window = args.window
+    window_requested = args.window
     while bv is None:
         try:
             bv = B.BatchVerifier(pk, n, m, window_bits=window)
@@ -750,7 +751,22 @@ def main():
         cstep(0)
         cdt = timed(cstep, csteps, torch, dist, coll_dev)
         assert int(d_cok.item()) == 0, "combined check rejected an all-valid batch"
+        # untimed: one tampered proof anywhere in the batch must flip the batch verdict
+        sc_cb = scs.copy()
+        sc_cb[(7 * Bsz) // 11, 2, 0] ^= np.uint64(1)
+        d_sc_cb = torch.from_numpy(np.ascontiguousarray(sc_cb).view(np.int64)).to(dev)
+        bv.run_combined_device(d_pts.data_ptr(), d_sc_cb.data_ptr(), Bsz, wkey, rank * Bsz, d_part.data_ptr(), d_cok.data_ptr(),
+                               d_cws.data_ptr(), cwsb, stream)
+        torch.cuda.synchronize()
+        assert int(d_cok.item()) == 1, "combined check accepted a batch holding a tampered proof"
+        del d_sc_cb
+        calg = Bsz * bv.msm_len * (2 * ((a.PW - 1) // 2 * 8) + 32)     # every MulVec term of every proof enters the one combination
         comb = {"value": world * Bsz * csteps / cdt, "unit": "verifies/s", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                "tamper_check": {"tampered": 1, "batch_verdict_flipped": True},
+                "roofline": {"bound": "hbm", "limiter": "alu", "kernel": "k_comb_* + k_var_* + k_fixed_msm<..., 1>: the whole step",
+                             "algorithmic_bytes_per_launch": calg, "kernel_ms": cdt / csteps * 1e3,
+                             "achieved": calg / (cdt / csteps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": calg / (cdt / csteps) / 1e9 / HBM_PEAK_GBS, "traffic": None},
                 "note": "random-linear-combination batch check (weights = SHA-256 PRF of a fresh 256-bit key and the global "
                         "proof index): batch verdict only, NOT the reference's per-proof verdicts; reported beside `value`, "
                         "never as it"}
@@ -1252,6 +1268,8 @@ def main():
             "data": "synthetic: %d distinct GPU-proved proofs per GPU in a batch of %d; reference constants as transcript" % (D, Bsz),
             "config": {"workload": "%s: n=%d m=%d range-proof verify, %s, batch %d per GPU, per-proof verdicts" % (args.config, n, m, args.curve, Bsz),
                        "curve": args.curve, "msm_terms_per_verify": N_msm, "window_bits": args.window,
+                       "window_bits_requested": window_requested,
+                       "window_narrowed_for_lack_of_hbm": args.window != window_requested,
                        "table_bytes": table_bytes_main,
                        "table_frac_of_hbm": table_bytes_main / float(torch.cuda.get_device_properties(dev).total_memory),
                        "parallelism": "proof-sharded x%d" % world,

@@ -53,12 +53,16 @@ def main():
     ap.add_argument("--windows", type=int, nargs="+", default=[0])
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--equal-scalars", action="store_true",
+                    help="the adversarial input of a bucket method: every scalar the same, so each window has ONE bucket holding all points")
     args = ap.parse_args()
     a = B.Arith.init(args.curve)
     dev = torch.device("cuda:0")
     for lg in args.log2n:
         n = 1 << lg
         sc, pts, ks, g = make_inputs(a, n)
+        if args.equal_scalars:
+            sc = np.broadcast_to(sc[3], sc.shape).copy()
         d_sc = torch.from_numpy(sc.view(np.int64)).to(dev)
         d_pt = torch.from_numpy(pts.view(np.int64)).to(dev)
         d_out = torch.zeros(a.PW, dtype=torch.int64, device=dev)
@@ -84,7 +88,7 @@ def main():
             ms = e0.elapsed_time(e1) / args.reps
             print(json.dumps({"curve": args.curve, "log2n": lg, "window_bits": c, "ms": round(ms, 4),
                               "points_per_s": round(n / ms * 1e3), "workspace_MB": round(wsb / 1e6, 1),
-                              "checked": exp is not None}), flush=True)
+                              "checked": exp is not None, "equal_scalars": bool(args.equal_scalars)}), flush=True)
             del d_ws
 
 
