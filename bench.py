@@ -28,7 +28,8 @@ The oracle is used only for that leg.  Beside `value` (never as it) the line als
 "tamper_check" (exact verdict vector of the bench batch with K tampered proofs), "latency" (B = 1 / 16 / 256),
 "prove" (batched device prover, device-resident), "serialized" (the same batch as proof containers + compressed
 commitments: decode with subgroup check + verify; and as version-2 containers with uncompressed points),
-"combined_check", "c3" (4096 x (64,1)), "hard_distribution", "other_curves" (secp256k1, edwards25519: the metric's shape,
+"combined_check", "grouped_check" (per-proof verdicts from one weighted check per group of 32 proofs + an exact pass over
+the groups that fail: all-valid and K-tampered batches), "c3" (4096 x (64,1)), "hard_distribution", "other_curves" (secp256k1, edwards25519: the metric's shape,
 the C3 shape and one proof alone), "production" (hashed generators + Fiat-Shamir transcript + blinding from a key +
 serialized input, with the stage split), "single_call" (RangeProof::prove / verify through the literal host-pointer API,
 ms per call), "msm" (MulVec::calculate as a device-resident seam: N = 2^16..2^22 points on the three curves, with
@@ -297,6 +298,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="wall seconds per CPU-baseline sample; 0 disables the CPU leg")
     ap.add_argument("--combined-steps", type=int, default=-1,
                     help="extra (separately timed) steps of the combined batch check; -1 = same as --steps, 0 = skip")
+    ap.add_argument("--grouped-steps", type=int, default=5,
+                    help="steps of the grouped check (per-proof verdicts from one weighted check per group); 0 = skip")
+    ap.add_argument("--group", type=int, default=32, help="proofs per group of the grouped check (a power of two)")
     ap.add_argument("--other-curves-steps", type=int, default=3,
                     help="steps per extra leg on the other two instantiations of the same kernels (edwards25519 -- the curve "
                          "under Ristretto255, which BASELINE.json's configs[1] names -- and secp256k1); 0 = skip")
@@ -771,6 +775,62 @@ def main():
                         "proof index): batch verdict only, NOT the reference's per-proof verdicts; reported beside `value`, "
                         "never as it"}
         del d_cws
+
+    # ---- secondary, separately timed: the grouped check -- PER-PROOF verdicts from one weighted check per group of 32
+    # neighbouring proofs, exact pass over the groups that fail (engine mode; include/bpp_amd.h "grouped check").
+    # Three batches: all valid (the case it is for), K tampered proofs scattered (K groups re-verified), and the verdict
+    # vector of the tampered batch compared with the exact path's expectation.
+    grouped = None
+    if args.grouped_steps > 0:
+        GROUP = args.group
+        gwsb = bv.grouped_workspace_bytes(Bsz, GROUP)
+        d_gws = torch.empty(gwsb, dtype=torch.uint8, device=dev)
+        d_gok = torch.full((Bsz,), 7, dtype=torch.int32, device=dev)
+        gkey = os.urandom(32)
+        gstats = [None]
+
+        def gstep_on(dp, ds):
+            def f(_i):
+                gstats[0] = bv.run_grouped_device(dp.data_ptr(), ds.data_ptr(), Bsz, gkey, rank * Bsz, d_gok.data_ptr(),
+                                                  d_gws.data_ptr(), gwsb, group=GROUP, stream=stream)
+            return f
+        gstep = gstep_on(d_pts, d_sc)
+        gstep(0)
+        gdt = timed(gstep, args.grouped_steps, torch, dist, coll_dev)
+        assert int(d_gok.sum().item()) == 0 and gstats[0] == (0, 0), "grouped check: a valid batch did not come back all Ok"
+        Kg = min(max(args.tampered, 1), Bsz)
+        rsg = np.random.RandomState(4242 + rank)
+        which_g = np.sort(rsg.choice(Bsz, size=Kg, replace=False))
+        sc_g = scs.copy()
+        for j, i in enumerate(which_g):
+            sc_g[i, j % 3, 0] ^= np.uint64(1 << (j % 60))
+        d_sc_g = torch.from_numpy(np.ascontiguousarray(sc_g).view(np.int64)).to(dev)
+        gstep_t = gstep_on(d_pts, d_sc_g)
+        gstep_t(0)
+        gdt_t = timed(gstep_t, args.grouped_steps, torch, dist, coll_dev)
+        got_g = d_gok.cpu().numpy()
+        want_g = np.zeros(Bsz, dtype=got_g.dtype)
+        want_g[which_g] = 1
+        assert np.array_equal(got_g, want_g), "grouped check: verdict vector differs from the exact path's"
+        groups_hit = len({int(i) // GROUP for i in which_g})
+        assert gstats[0] == (groups_hit, groups_hit * GROUP), "grouped check: unexpected statistics %r" % (gstats[0],)
+        galg = Bsz * bv.msm_len * (2 * ((a.PW - 1) // 2 * 8) + 32)
+        gms = gdt / args.grouped_steps * 1e3
+        grouped = {"value": world * Bsz * args.grouped_steps / gdt, "unit": "verifies/s", "steps": args.grouped_steps,
+                   "ms_per_step": gms, "group": GROUP, "verdicts": "per proof",
+                   "with_tampered": {"tampered": int(Kg), "groups_failed": groups_hit, "proofs_reverified": groups_hit * GROUP,
+                                     "value": world * Bsz * args.grouped_steps / gdt_t, "unit": "verifies/s",
+                                     "ms_per_step": gdt_t / args.grouped_steps * 1e3, "verdicts_exact": True},
+                   "roofline": {"bound": "hbm", "limiter": "alu",
+                                "kernel": "k_comb_* + k_var_* + k_fixed_msm<..., 0> over the groups: the whole step",
+                                "algorithmic_bytes_per_launch": galg, "kernel_ms": gms,
+                                "achieved": galg / gms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": galg / gms / 1e6 / HBM_PEAK_GBS, "traffic": None},
+                   "note": "per-proof verdicts: one weighted check per group of %d neighbouring proofs (weights = SHA-256 PRF of a "
+                           "fresh 256-bit key and the global proof index), then the exact per-proof path over the proofs of the "
+                           "groups that failed; the verdict vector is the exact path's except with probability ~2^-128 per group.  "
+                           "NOT the reference's deterministic per-proof check: reported beside `value`, never as it" % GROUP}
+        del d_gws, d_sc_g, d_gok
 
     msm_len_main, table_bytes_main = bv.msm_len, bv.table_bytes
 
@@ -1298,6 +1358,7 @@ def main():
             "prove": prove,
             "serialized": serialized,
             "combined_check": comb,
+            "grouped_check": grouped,
             "c3": c3,
             "hard_distribution": hard,
             "other_curves": others,

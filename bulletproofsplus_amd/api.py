@@ -601,6 +601,34 @@ def _verifier_run_combined_device(self, d_points: int, d_scalars: int, count: in
           "bpp_verifier_run_combined")
 
 
+def _verifier_grouped_workspace_bytes(self, count: int, group: int = 32) -> int:
+    return _lib.lib().bpp_verifier_grouped_workspace_bytes(self.handle, count, group)
+
+
+def _verifier_run_grouped_device(self, d_points: int, d_scalars: int, count: int, weight_key, index_base: int,
+                                 d_out_verdicts: int, d_workspace: int, workspace_bytes: int, group: int = 32,
+                                 stream: int = 0, d_challenges: int = 0, d_weights: int = 0):
+    """Per-proof verdicts (the vector run_device writes) from one weighted check per group of `group` neighbouring proofs
+    and an exact pass over the proofs of the groups that fail (include/bpp_amd.h "grouped check"; an engine mode, not a
+    reference path).  weight_key / d_weights as for run_combined_device.  Synchronises the stream.
+    Returns (groups that failed, proofs re-verified exactly)."""
+    if d_weights:
+        key = None
+    else:
+        if weight_key is None:
+            import os
+            weight_key = os.urandom(32)
+        key = bytes(weight_key)
+        if len(key) != 32:
+            raise ValueError("weight_key must be 32 bytes")
+    stats = (ctypes.c_uint64 * 2)()
+    check(_lib.lib().bpp_verifier_run_grouped(self.handle, d_points, d_scalars, count, d_challenges or None, key,
+                                              ctypes.c_uint64(index_base), d_weights or None, group, d_out_verdicts, stats,
+                                              d_workspace, workspace_bytes, stream or None),
+          "bpp_verifier_run_grouped")
+    return int(stats[0]), int(stats[1])
+
+
 def _verifier_derive_challenges_device(self, d_points: int, count: int, d_challenges: int, stream: int = 0):
     """Fiat-Shamir challenges [y, z, e, e_1..e_k] of every proof record of a resident batch (csrc/transcript.hpp),
     in the layout run_device takes as d_challenges.  The reference has no transcript: parity unpinned."""
@@ -673,6 +701,8 @@ BatchVerifier.prove_batch_device = _engine_prove_batch_device
 BatchVerifier.partial_bytes = _verifier_partial_bytes
 BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device
+BatchVerifier.grouped_workspace_bytes = _verifier_grouped_workspace_bytes
+BatchVerifier.run_grouped_device = _verifier_run_grouped_device
 BatchVerifier.derive_challenges_device = _verifier_derive_challenges_device
 BatchVerifier.sum_partials_device = _verifier_sum_partials_device
 def _verifier_set_subgroup_check(self, on: bool):

@@ -457,6 +457,30 @@ extern "C" int bpp_verifier_run_combined(bpp_verifier* v, const uint64_t* d_poin
                                                       workspace_bytes, static_cast<hipStream_t>(stream));
     });
 }
+// ---- grouped check: per-proof verdicts, one weighted check per group, exact pass over the failing groups ------
+extern "C" size_t bpp_verifier_grouped_workspace_bytes(const bpp_verifier* v, size_t count, uint32_t group) {
+    if (!v || group < 2 || (group & (group - 1))) return 0;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::group_layout(v->s, count, group).total;
+        return 0;
+    });
+    return r;
+}
+extern "C" int bpp_verifier_run_grouped(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                        const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                                        const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts,
+                                        uint64_t* stats, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !d_out_verdicts || !d_workspace || (count && (!d_points || !d_scalars)))
+        return fail(BPP_E_ARG, "null argument");
+    if (!weight_key && !d_weights) return fail(BPP_E_ARG, "the grouped check needs a weight key or a weight buffer");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::run_grouped(v, d_points, d_scalars, count, d_challenges, weight_key, index_base,
+                                                     d_weights, group, d_out_verdicts, stats, d_workspace, workspace_bytes,
+                                                     static_cast<hipStream_t>(stream));
+    });
+}
 extern "C" int bpp_verifier_sum_partials(bpp_verifier* v, const void* d_partials, size_t n, uint32_t* d_ok,
                                          void* stream) {
     if (!v || !d_partials || !d_ok) return fail(BPP_E_ARG, "null argument");

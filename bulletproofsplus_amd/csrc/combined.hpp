@@ -125,22 +125,93 @@ __global__ void __launch_bounds__(256) k_comb_fixed(VerifyShape s, const uint32_
 }
 
 // out[g][j] = sum over the proofs p of group g (p = g * group + t, t < group, p < count) of in[p][j]
-// (jacobian window sums, var_wsums<C>() per proof); one lane per (g, j)
+// (jacobian window sums, `per` of them per proof); one lane per (g, j)
 template <class C>
 __global__ void __launch_bounds__(64) k_comb_window_fold(const uint32_t* __restrict__ in, size_t count, uint32_t group,
-                                                         uint32_t* __restrict__ out, size_t n_out) {
+                                                         uint32_t* __restrict__ out, size_t n_out, uint32_t per) {
     constexpr int JW = jac_words<C>();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    const size_t g = i / var_wsums<C>();
-    const uint32_t j = (uint32_t)(i % var_wsums<C>());
+    const size_t g = i / per;
+    const uint32_t j = (uint32_t)(i % per);
     Jac<C> acc = jac_inf<C>();
     for (uint32_t t = 0; t < group; t++) {
         const size_t p = g * group + t;
         if (p >= count) break;
-        acc = jac_add(acc, jac_ldg<C>(in + (p * var_wsums<C>() + j) * JW));
+        acc = jac_add(acc, jac_ldg<C>(in + (p * per + j) * JW));
     }
     jac_stg<C>(out + i * JW, acc);
+}
+
+// ---- grouped check: one weighted check per group of `group` neighbouring proofs ---------------------------------
+// A batch whose proofs are (nearly) all valid gets its per-proof verdicts at the combined check's price: group g's
+// proofs p = g group .. are checked together, sum_p w_p M_p == identity, as ONE virtual proof of the batch verifier
+// (its scalars: rows[g], below; its proof-point window sums: the group's, added by k_comb_window_fold), and only the
+// proofs of a group that FAILS go through the exact per-proof path afterwards.  The verdicts are the exact path's unless a
+// group of proofs, not all valid, passes its weighted check: probability ~2^-128 per group under the same conditions as
+// the combined check above (unpredictable weights, proof points in the prime-order subgroup).
+
+// rows[g][fixed_term_index(f)] = canonical(sum_{p in group g} w_p * s[p][fixed_term_index(f)]): one lane per (g, f), f
+// fastest, so that a wave reads 64 neighbouring scalars of one proof at a time and the weight is wave-uniform
+template <class C>
+__global__ void __launch_bounds__(64) k_comb_fixed_grouped(VerifyShape s, const uint32_t* __restrict__ scalars,
+                                                           const uint32_t* __restrict__ weights, size_t count,
+                                                           uint32_t group, uint32_t* __restrict__ rows) {
+    using P = typename C::Fr;
+    using F = Fe<P>;
+    const uint32_t bpg = (s.NF + 63) / 64;
+    const size_t g = blockIdx.x / bpg;
+    const uint32_t f = (blockIdx.x % bpg) * 64 + threadIdx.x;
+    if (f >= s.NF) return;
+    const uint32_t idx = fixed_term_index(s, f);
+    F acc = F::zero();
+    for (uint32_t t = 0; t < group; t++) {
+        const size_t p = g * group + t;
+        if (p >= count) break;
+        uint32_t w[8];
+        ld_words<8>(scalars + (p * s.N + idx) * 8, w);
+        const F x = fe_from_canonical<P>(w);
+        ld_words<8>(weights + p * 8, w);
+        acc = fe_add(acc, fe_mul(x, fe_load<P>(w)));
+    }
+    uint32_t w[8];
+    fe_to_canonical(acc, w);
+    st_words<8>(rows + (g * s.N + idx) * 8, w);
+}
+
+// gbad[g] = any proof of group g carried an invalid point
+static __global__ void __launch_bounds__(256) k_comb_group_bad(const uint32_t* __restrict__ bad, size_t count, uint32_t group,
+                                                        uint32_t* __restrict__ gbad, size_t groups) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    uint32_t any = 0;
+    for (uint32_t t = 0; t < group; t++) {
+        const size_t p = g * group + t;
+        if (p < count) any |= bad[p];
+    }
+    gbad[g] = any ? 1u : 0u;
+}
+
+// verdicts[p] = its group's verdict (0 = every proof of the group is valid; 1 = stands until the exact pass overwrites it)
+static __global__ void __launch_bounds__(256) k_comb_group_spread(const uint32_t* __restrict__ gok, uint32_t group,
+                                                           uint32_t* __restrict__ verdicts, size_t count) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < count) verdicts[p] = gok[p / group] ? 1u : 0u;
+}
+
+// out[i][0..row) = in[list[i]][0..row): one block per row
+static __global__ void k_comb_gather_rows(const uint32_t* __restrict__ in, const uint32_t* __restrict__ list, uint32_t row,
+                                   uint32_t* __restrict__ out) {
+    const uint32_t* src = in + (size_t)list[blockIdx.x] * row;
+    uint32_t* dst = out + (size_t)blockIdx.x * row;
+    for (uint32_t t = threadIdx.x; t < row; t += blockDim.x) dst[t] = src[t];
+}
+
+// out[list[i]] = in[i]
+static __global__ void __launch_bounds__(256) k_comb_scatter_words(const uint32_t* __restrict__ in, const uint32_t* __restrict__ list,
+                                                            uint32_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[list[i]] = in[i];
 }
 
 // verdict of one rank's share: ok = partial is the identity and no proof carried an invalid point

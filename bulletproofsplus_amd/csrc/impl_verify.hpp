@@ -121,6 +121,15 @@ struct VerifyImpl {
                    const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
                    uint64_t* d_out_scalars, uint64_t* d_out_result, hipStream_t st);
 
+    // form of the Horner stage for a pass over `count` proofs (k_fixed_msm's horner_tree: 0, 1 or 2)
+    static uint32_t horner_form(const VerifyShape& s, size_t count) {
+        const bool small_job = (double)count * ((double)s.NF * s.W / 7.0e9 + 9.2e-8) < 2.0e-3;
+        return count <= HORNER_TREE_MAX ? 1u : (small_job ? 2u : 0u);
+    }
+    static int finish(bpp_verifier* v, uint8_t* ws, const WsLayout& L, size_t count, const uint32_t* w_sc,
+                      const uint32_t* w_vw, const uint32_t* w_bad, uint32_t* d_ok, uint32_t* d_out_result, uint32_t tree,
+                      bool lone, hipStream_t st, hipEvent_t* ev);
+
     static int derive_challenges(bpp_verifier* v, const uint64_t* d_points, size_t count, uint64_t* d_challenges,
                                  hipStream_t st);
 
@@ -199,6 +208,74 @@ struct VerifyImpl {
                             const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
                             const uint64_t* d_weights, uint32_t* d_out_partial, uint32_t* d_ok, void* d_workspace,
                             size_t workspace_bytes, hipStream_t st);
+
+    // ---- grouped check (combined.hpp): per-proof verdicts from one weighted check per GROUP of proofs ------
+    struct GroupLayout {
+        size_t pts, bad, scalars, prep, weights, var_sc, vdig, vtbl, vscr, vwsum, vfold,   // per proof, as the combined check's
+            grows, gbad, gok, tail,                                                         // per group
+            list, x_pts, x_sc, x_ch, x_ok, x_run,                                           // the exact second pass
+            total;
+        size_t groups, slice;
+    };
+    static constexpr size_t GROUP_EXACT_SLICE = 2048;   // proofs of failing groups re-verified per exact pass
+    static GroupLayout group_layout(const VerifyShape& s, size_t count, uint32_t group) {
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        GroupLayout w;
+        const size_t items = count * s.NV;
+        w.groups = cdiv(count, group);
+        w.slice = std::min<size_t>(std::max<size_t>(count, 1), GROUP_EXACT_SLICE);
+        size_t o = 0;
+        w.pts = o;
+        o += al(items * 2 * N * 4);
+        w.bad = o;
+        o += al(count * 4);
+        w.scalars = o;
+        o += al(count * (size_t)s.N * 32);
+        w.prep = o;
+        o += al(count * vs_prep_bytes<C>(s));
+        w.weights = o;
+        o += al(count * 32);
+        w.var_sc = o;
+        o += al(items * 32);
+        w.vdig = o;
+        o += al(items * VAR_DIGIT_STRIDE);
+        w.vtbl = o;
+        o += al(items * VAR_MULTIPLES * 2 * N * 4);
+        w.vscr = o;
+        o += al(items * 2 * (VAR_MULTIPLES - 1) * N * 4);
+        w.vwsum = o;
+        o += al(count * var_wsums<C>() * JW * 4);
+        w.vfold = o;
+        o += al((size_t)cdiv(count, 2) * var_wsums<C>() * JW * 4);
+        w.grows = o;
+        o += al(w.groups * (size_t)s.N * 32);
+        w.gbad = o;
+        o += al(w.groups * 4);
+        w.gok = o;
+        o += al(w.groups * 4);
+        w.tail = o;
+        o += ws_layout(s, w.groups).total;
+        w.list = o;
+        o += al(w.slice * 4);
+        w.x_pts = o;
+        o += al(w.slice * s.NV * WW * 4);
+        w.x_sc = o;
+        o += al(w.slice * 96);
+        w.x_ch = o;
+        o += al(w.slice * (size_t)(3 + s.k) * 32);
+        w.x_ok = o;
+        o += al(w.slice * 4);
+        w.x_run = o;
+        o += ws_layout(s, w.slice).total;
+        w.total = o;
+        return w;
+    }
+    // d_out_verdicts: count words, 0 = Ok / 1 = VerificationError, as bpp_verifier_run writes them.  h_stats (host, may be
+    // null): [groups that failed their weighted check, proofs re-verified by the exact pass].  Synchronises `st`.
+    static int run_grouped(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                           const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                           const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
+                           void* d_workspace, size_t workspace_bytes, hipStream_t st);
 
     // ---- batched prover (prover_batch.hpp) -------------------------------------------------------------
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
@@ -347,8 +424,6 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     uint32_t* w_bad = reinterpret_cast<uint32_t*>(ws + L.bad);
     uint32_t* w_sc = d_out_scalars ? reinterpret_cast<uint32_t*>(d_out_scalars)
                                    : reinterpret_cast<uint32_t*>(ws + L.scalars);
-    uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
-    uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
     uint32_t* w_vt = reinterpret_cast<uint32_t*>(ws + L.vtbl);
     const unsigned bpp_ = blocks_per_proof(s, count);
     const size_t npts = count * s.NV;
@@ -399,8 +474,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     // otherwise wait for the one-lane chains: the chain is ~2 ms, the eight-lane form costs ~0.09 us of chip time per
     // proof on top of the fixed-generator work (~7 G mixed additions/s) -- measured on (64,1): better at 4 096 proofs,
     // worse at 8 192
-    const bool small_job = (double)count * ((double)s.NF * s.W / 7.0e9 + 9.2e-8) < 2.0e-3;
-    const uint32_t tree = count <= HORNER_TREE_MAX ? 1u : (small_job ? 2u : 0u);
+    const uint32_t tree = horner_form(s, count);
     // a launch whose blocks are all resident at once (<= 1024): only latency counts -- its blocks also sum their own
     // partials (mode 3 of k_fixed_msm) and the points of a proof are dealt to VAR_GROUPS lanes per window
     const bool lone = tree == 1 && count * bpp_ <= 1024;
@@ -416,6 +490,20 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes, tree == 1 ? 1u : 0u, vgroups);
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM + 1, st));
+    return finish(v, ws, L, count, w_sc, w_vw, w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result), tree, lone, st, ev);
+}
+
+// The rest of a pass, from the scalars [count][N] and the proof points' window sums: the fixed-generator MulVec with the
+// Horner stage in its leading blocks, the folds of its partials, the verdicts.  ws / L: a workspace laid out for `count`.
+template <class C>
+int VerifyImpl<C>::finish(bpp_verifier* v, uint8_t* ws, const WsLayout& L, size_t count, const uint32_t* w_sc,
+                          const uint32_t* w_vw, const uint32_t* w_bad, uint32_t* d_ok, uint32_t* d_out_result, uint32_t tree,
+                          bool lone, hipStream_t st, hipEvent_t* ev) {
+    const VerifyShape& s = v->s;
+    const unsigned bpp_ = blocks_per_proof(s, count);
+    uint32_t* w_fp = reinterpret_cast<uint32_t*>(ws + L.fpart);
+    uint32_t* w_vp = reinterpret_cast<uint32_t*>(ws + L.vpart);
+    auto mark = [&](int idx, hipStream_t s_) { return ev ? hipEventRecord(ev[idx], s_) : hipSuccess; };
     HIPCHK(mark(2 * BPP_STAGE_FIXED_MSM, st));
     const unsigned hb = tree == 1 ? (unsigned)count : cdiv(count, tree == 2 ? FIXED_BLOCK / 8 : FIXED_BLOCK);
     uint32_t* w_ft = reinterpret_cast<uint32_t*>(ws + L.fthread);
@@ -434,7 +522,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
             hipLaunchKernelGGL(k_partials_fold<C>, dim3(cdiv(count * folded, 64)), dim3(64), 0, st, w_ft, FOLD_GROUP, w_fp,
                                count * folded);
         hipLaunchKernelGGL(k_finalize_tree<C>, dim3((unsigned)count), dim3(64), 0, st, lone ? w_ft : w_fp,
-                           lone ? bpp_ : folded, w_vp, w_bad, d_ok, reinterpret_cast<uint32_t*>(d_out_result), count);
+                           lone ? bpp_ : folded, w_vp, w_bad, d_ok, d_out_result, count);
         HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
         HIPCHK(hipGetLastError());
         return BPP_OK;
@@ -453,7 +541,7 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
         w_last = w_fp3;
     }
     hipLaunchKernelGGL(k_finalize<C>, dim3(cdiv(count, 64)), dim3(64), 0, st, w_last, last, w_vp, 1u, w_bad, d_ok,
-                       reinterpret_cast<uint32_t*>(d_out_result), count);
+                       d_out_result, count);
     HIPCHK(mark(2 * BPP_STAGE_FINALIZE + 1, st));
     HIPCHK(hipGetLastError());
     return BPP_OK;
@@ -556,7 +644,7 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     for (size_t nrem = count; nrem > 1;) {
         const size_t groups = cdiv(nrem, COMB_FOLD_GROUP);
         hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(groups * var_wsums<C>(), 64)), dim3(64), 0, st, cur, nrem,
-                           COMB_FOLD_GROUP, nxt, groups * var_wsums<C>());
+                           COMB_FOLD_GROUP, nxt, groups * var_wsums<C>(), var_wsums<C>());
         std::swap(cur, nxt);
         nrem = groups;
     }
@@ -568,6 +656,111 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
                        d_out_partial);
     hipLaunchKernelGGL(k_comb_verdict<C>, dim3(1), dim3(256), 0, st, d_out_partial, w_bad, count, d_ok);
     HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+template <class C>
+int VerifyImpl<C>::run_grouped(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                               const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                               const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
+                               void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+    const VerifyShape& s = v->s;
+    if (group < 2 || (group & (group - 1))) return fail(BPP_E_ARG, "group must be a power of two, at least 2");
+    const GroupLayout L = group_layout(s, count, group);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    if (count * s.NV >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "count too large");
+    if (h_stats) h_stats[0] = h_stats[1] = 0;
+    if (count == 0) return BPP_OK;
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+    uint32_t *w_pts = W(L.pts), *w_bad = W(L.bad), *w_sc = W(L.scalars), *w_wt = W(L.weights), *w_vs = W(L.var_sc);
+    uint32_t *w_vt = W(L.vtbl), *w_vw = W(L.vwsum), *w_vf = W(L.vfold), *w_rows = W(L.grows), *w_gbad = W(L.gbad);
+    uint32_t* w_gok = W(L.gok);
+    uint8_t* w_vd = ws + L.vdig;
+    const size_t items = count * s.NV, G = L.groups;
+    // ---- pass 1: one weighted check per group, through the batch verifier's own last stages at count = G --------
+    HIPCHK(zero_words_async(w_bad, count * 4, st));
+    hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
+                       reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
+    const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
+    const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
+    {
+        int rc_vs = launch_verify_scalars<C>(s, reinterpret_cast<const uint32_t*>(d_scalars), ch, ch_stride, w_sc, count,
+                                             W(L.prep), st);
+        if (rc_vs) return rc_vs;
+    }
+    WeightKey wk;
+    for (int i = 0; i < 8; i++)
+        wk.w[i] = d_weights ? 0u
+                            : (uint32_t)weight_key[4 * i] | ((uint32_t)weight_key[4 * i + 1] << 8) |
+                                  ((uint32_t)weight_key[4 * i + 2] << 16) | ((uint32_t)weight_key[4 * i + 3] << 24);
+    hipLaunchKernelGGL(k_comb_weights<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, wk, index_base,
+                       reinterpret_cast<const uint32_t*>(d_weights), w_wt, count);
+    hipLaunchKernelGGL(k_comb_fixed_grouped<C>, dim3((unsigned)(G * cdiv(s.NF, 64))), dim3(64), 0, st, s, w_sc, w_wt, count,
+                       group, w_rows);
+    hipLaunchKernelGGL(k_comb_group_bad, dim3(cdiv(G, 256)), dim3(256), 0, st, w_bad, count, group, w_gbad, G);
+    const uint32_t tree = horner_form(s, G);
+    const uint32_t per = tree == 1 ? var_wsums<C>() : var_windows<C>();   // window sums per proof, in the layout the Horner form reads
+    hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
+    hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
+    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, W(L.vscr), items);
+    const size_t vlanes = count * per;
+    hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
+                       vlanes, tree == 1 ? 1u : 0u, 1u);
+    uint32_t* cur = w_vw;
+    uint32_t* nxt = w_vf;
+    size_t nrem = count;
+    for (uint32_t left = group; left > 1;) {   // the proofs of a group are neighbours: 4 (at last 2) to 1 per level
+        const uint32_t step = left >= 4 ? 4u : 2u;
+        const size_t outn = cdiv(nrem, step);
+        hipLaunchKernelGGL(k_comb_window_fold<C>, dim3(cdiv(outn * per, 64)), dim3(64), 0, st, cur, nrem, step, nxt, outn * per,
+                           per);
+        std::swap(cur, nxt);
+        nrem = outn;
+        left /= step;
+    }
+    {
+        const WsLayout T = ws_layout(s, G);
+        int rc = finish(v, ws + L.tail, T, G, w_rows, cur, w_gbad, w_gok, nullptr, tree, false, st, nullptr);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_comb_group_spread, dim3(cdiv(count, 256)), dim3(256), 0, st, w_gok, group, d_out_verdicts, count);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> gok(G);
+    HIPCHK(hipMemcpyAsync(gok.data(), w_gok, G * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // ---- pass 2: the proofs of the groups that failed, exactly, through the per-proof path ------------------------
+    std::vector<uint32_t> list;
+    size_t failed = 0;
+    for (size_t g = 0; g < G; g++)
+        if (gok[g]) {
+            failed++;
+            for (size_t p = g * group; p < std::min(count, (g + 1) * (size_t)group); p++) list.push_back((uint32_t)p);
+        }
+    if (h_stats) {
+        h_stats[0] = failed;
+        h_stats[1] = list.size();
+    }
+    const uint32_t row_pts = s.NV * WW, row_sc = 24, row_ch = (3 + s.k) * 8;
+    for (size_t lo = 0; lo < list.size(); lo += L.slice) {
+        const size_t cnt = std::min(L.slice, list.size() - lo);
+        HIPCHK(hipMemcpyAsync(W(L.list), list.data() + lo, cnt * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_comb_gather_rows, dim3((unsigned)cnt), dim3(256), 0, st,
+                           reinterpret_cast<const uint32_t*>(d_points), W(L.list), row_pts, W(L.x_pts));
+        hipLaunchKernelGGL(k_comb_gather_rows, dim3((unsigned)cnt), dim3(64), 0, st,
+                           reinterpret_cast<const uint32_t*>(d_scalars), W(L.list), row_sc, W(L.x_sc));
+        if (d_challenges)
+            hipLaunchKernelGGL(k_comb_gather_rows, dim3((unsigned)cnt), dim3(64), 0, st,
+                               reinterpret_cast<const uint32_t*>(d_challenges), W(L.list), row_ch, W(L.x_ch));
+        int rc = run(v, reinterpret_cast<const uint64_t*>(ws + L.x_pts), reinterpret_cast<const uint64_t*>(ws + L.x_sc), cnt,
+                     d_challenges ? reinterpret_cast<const uint64_t*>(ws + L.x_ch) : nullptr, W(L.x_ok), ws + L.x_run,
+                     workspace_bytes - L.x_run, nullptr, nullptr, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_comb_scatter_words, dim3(cdiv(cnt, 256)), dim3(256), 0, st, W(L.x_ok), W(L.list), d_out_verdicts,
+                           cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));   // `list` slices are staged from pageable memory
+    }
     return BPP_OK;
 }
 

@@ -70,6 +70,7 @@ struct PipShape {
     uint32_t L, cpw, capseg;   // entries per chunk, chunks per window, segment slots per window
     uint32_t fb;               // log2 of the buckets per coarse bin of the sort (5..8)
     uint32_t fl;               // lanes per bucket in k_pip_fold (1, 2, 4 or 8)
+    uint32_t istride;          // entries per row of `sorted`: items rounded up to 4 (rows start 16-byte aligned for the entry DMA)
     uint32_t bias[10];         // sum over the signed windows of half their range at their offset
 
     __host__ __device__ uint32_t width(uint32_t j) const { return q + (j < nwide ? 1u : 0u); }
@@ -93,6 +94,7 @@ inline int pip_shape(size_t n, int c, bool glv, const uint32_t* max_words, int b
     s.n = (uint32_t)n;
     s.glv = glv ? 1u : 0u;
     s.items = (uint32_t)(glv ? 2 * n : n);
+    s.istride = (s.items + 3u) & ~3u;
     s.c = (uint32_t)c;
     s.W = (uint32_t)((bits + c - 1) / c);
     s.q = (uint32_t)bits / s.W;
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const 
     __syncthreads();
     cnt[t] = ex;   // cursors
     __syncthreads();
-    uint32_t* so = sorted + (size_t)j * s.items + lo;
+    uint32_t* so = sorted + (size_t)j * s.istride + lo;
     for (uint32_t r = t; r < n; r += 4 * blockDim.x) {
         uint32_t lw[4], it[4];
 #pragma unroll
@@ -523,12 +525,14 @@ __global__ void __launch_bounds__(1024) k_pip_segments(PipShape s, const uint32_
 // segment slot of (bucket, chunk) whenever the bucket changes and at the chunk's end.  The points are gathered by
 // LDS-DMA (glds16, kernels.hpp) into a two-deep per-lane ring, one addition ahead, exactly as k_fixed_msm gathers its
 // table entries: all lanes of a wave step together, a lane past its last entry DMAs a dummy line, and a counted
-// s_waitcnt vmcnt is all the synchronisation the ring needs (any further VMEM operation in flight -- the entry
-// prefetch, the bucket bookkeeping, a flush -- only makes the count more conservative).
+// s_waitcnt vmcnt is all the synchronisation the ring needs (any further VMEM operation in flight -- the bucket
+// bookkeeping, a flush -- only makes the count more conservative).  The sorted entries themselves travel the same way,
+// four per lane per DMA, one batch ahead: a plain load of the next entry inside the loop made the compiler wait for
+// EVERYTHING in flight -- the point just requested included -- before every step.
 constexpr unsigned PIP_BLOCK = 128;
 template <class C>
 constexpr unsigned pip_ring_bytes() {
-    return (PIP_BLOCK / 64) * (2 * (2 * C::Fp::N / 4)) * 1024;
+    return (PIP_BLOCK / 64) * (2 * (2 * C::Fp::N / 4) + 2) * 1024;   // two point slots + two slots of four sorted entries per lane
 }
 template <class C>
 __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipShape s, const uint32_t* __restrict__ points,
@@ -542,7 +546,7 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
     constexpr int N = C::Fp::N;
     constexpr int JW = jac_words<C>();
     constexpr int CH = 2 * N / 4;                 // 16-byte pieces of a point
-    constexpr int WAVE_WORDS = 2 * CH * 256;      // LDS words of one wave's ring
+    constexpr int WAVE_WORDS = (2 * CH + 2) * 256;   // LDS words of one wave: the point ring + two batches of sorted entries
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t bpw = (s.cpw + PIP_BLOCK - 1) / PIP_BLOCK;   // blocks never straddle windows
     const uint32_t j = blockIdx.x / bpw;
@@ -552,8 +556,10 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
     const uint32_t k = k0 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* ring = lds + (threadIdx.x >> 6) * WAVE_WORDS;
+    uint32_t* ebuf = ring + 2 * CH * 256;                        // [2][lane][4 entries]
     const uint32_t ring_addr = (uint32_t)reinterpret_cast<uintptr_t>(ring);
-    const uint32_t* row = sorted + (size_t)j * s.items;
+    const uint32_t ebuf_addr = ring_addr + 2 * CH * 1024;
+    const uint32_t* row = sorted + (size_t)j * s.istride;
     const uint32_t bb = s.bbase(j);
     const uint32_t pos0 = (uint64_t)k * s.L < total ? k * s.L : total;
     const uint32_t stop = min(pos0 + s.L, total);           // pos0 >= stop: a lane without entries
@@ -565,23 +571,32 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
         bend = o + counts[bb + b];
         seg = segs + ((size_t)j * s.capseg + segbase[bb + b] + (k - o / s.L)) * JW;
     }
+    // batch q = this lane's entries 4 q .. 4 q + 3 (16 bytes, 16-byte aligned: pos0 is a multiple of L >= 8 and rows start
+    // aligned) -> entry slot q & 1.  A batch is requested four steps before its first entry is needed.
+    auto dma_entries = [&](uint32_t q) {
+        const uint32_t p = pos0 + 4 * q;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous batch has been read out
+        glds16(row + (p < stop ? p : 0), ebuf_addr + (q & 1u) * 1024);
+    };
     uint32_t nbits = 0;
-    uint32_t e_next = row[pos0 < stop ? pos0 : 0];   // the sorted entry of the NEXT step to issue: its load rides under an addition
     auto issue = [&](uint32_t t) {
         const uint32_t slot = t & 1u;
         const uint32_t p = pos0 + t;
+        if ((t & 3u) == 0) dma_entries((t >> 2) + 1);
+        const uint32_t e = ebuf[((t >> 2) & 1u) * 256 + lane * 4 + (t & 3u)];
         const uint32_t* src = points;   // dummy line
         uint32_t neg = 0;
         if (p < stop) {
-            src = points + (size_t)(e_next >> 1) * 2 * N;
-            neg = e_next & 1u;
+            src = points + (size_t)(e >> 1) * 2 * N;
+            neg = e & 1u;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous point has been read out
 #pragma unroll
         for (int kk = 0; kk < CH; kk++) glds16(src + 4 * kk, ring_addr + (slot * CH + kk) * 1024);
         nbits = (nbits & ~(1u << slot)) | (neg << slot);
-        e_next = row[p + 1 < stop ? p + 1 : 0];
     };
+    dma_entries(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     Xyzz<C> acc = xyzz_inf<C>();
     issue(0);
     issue(1);
@@ -822,7 +837,7 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     w.rec_low = o;
     o += al((size_t)s.W * s.items * 2);
     w.sorted = o;
-    o += al((size_t)s.W * s.items * 4 + 16);
+    o += al((size_t)s.W * s.istride * 4 + 64);
     const size_t ncb = pip_ncoarse_total(s);
     w.ccount = o;
     o += al(ncb * 4);

@@ -245,6 +245,24 @@ int bpp_verifier_run_combined(bpp_verifier *v, const uint64_t *d_points, const u
  * rank reported an invalid point */
 int bpp_verifier_sum_partials(bpp_verifier *v, const void *d_partials, size_t n, uint32_t *d_ok, void *stream);
 
+/* ---- grouped check -- per-proof verdicts at (nearly) the combined check's price; an engine mode, NOT a reference path ----
+ * The reference verifies one proof at a time (src/range/mod.rs:57-78).  A service that needs the verdict of EVERY proof
+ * but expects nearly all of them to be valid does not have to pay the per-proof MulVec: neighbouring proofs are checked
+ * in groups of `group` (a power of two >= 2; 32 is a good default), sum_{p in group} w_p * M_p == identity, each group as
+ * ONE virtual proof of the batch verifier's last stages, and only the proofs of a group that fails go through the exact
+ * per-proof path (bpp_verifier_run) afterwards.  Weights, their key and index_base as for bpp_verifier_run_combined, and
+ * the same conditions: a group holding an invalid proof passes with probability ~2^-128 if the weights were unpredictable
+ * and the proof points lie in the prime-order subgroup (bpp_verifier_set_subgroup_check / the serialized path).
+ *   d_out_verdicts : count x uint32_t, 0 = Ok / 1 = VerificationError -- the vector bpp_verifier_run writes
+ *   stats          : HOST pointer, may be NULL: [groups that failed, proofs re-verified exactly]
+ * The call synchronises `stream` (the list of failing groups comes back to the host between the two passes), so it
+ * cannot be captured into a graph. */
+size_t bpp_verifier_grouped_workspace_bytes(const bpp_verifier *v, size_t count, uint32_t group);
+int bpp_verifier_run_grouped(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                             const uint64_t *d_challenges, const uint8_t *weight_key, uint64_t index_base,
+                             const uint64_t *d_weights, uint32_t group, uint32_t *d_out_verdicts, uint64_t *stats,
+                             void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* ---- Fiat-Shamir transcript (csrc/transcript.hpp) -- what the reference's constants stand in for --------
  * The reference has no transcript (every challenge is a literal, src/range/mod.rs:278-279,
  * :417-418, src/weighted_inner_product_proof.rs:131, :211, :353, :369; the intended labels survive as a comment at

@@ -65,3 +65,26 @@ def run_combined_device(torch, bv, records, scalars, seed=12345, index_base=0, w
                            d_weights=d_w.data_ptr() if d_w is not None else 0)
     torch.cuda.synchronize()
     return int(d_ok.item()), d_part.cpu().numpy()
+
+
+def run_grouped_device(torch, bv, records, scalars, group, seed=12345, index_base=0, challenges=None):
+    """Grouped check on device -> (verdicts (count,) u32, groups failed, proofs re-verified exactly).  Weight key from
+    `seed` (repeatable; production callers pass os.urandom(32))."""
+    import hashlib
+    dev = torch.device("cuda:0")
+    count = records.shape[0]
+    d_pts = torch.from_numpy(np.ascontiguousarray(records).view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(np.ascontiguousarray(scalars).view(np.int64)).to(dev)
+    d_ok = torch.full((max(count, 1),), 7, dtype=torch.int32, device=dev)
+    wsb = bv.grouped_workspace_bytes(count, group)
+    d_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+    key = hashlib.sha256(b"test weight key %d" % seed).digest()
+    d_ch = None
+    if challenges is not None:
+        d_ch = torch.from_numpy(np.ascontiguousarray(challenges).view(np.int64)).to(dev)
+    failed, redone = bv.run_grouped_device(d_pts.data_ptr(), d_sc.data_ptr(), count, key, index_base, d_ok.data_ptr(),
+                                           d_ws.data_ptr(), wsb, group=group,
+                                           stream=torch.cuda.current_stream().cuda_stream,
+                                           d_challenges=d_ch.data_ptr() if d_ch is not None else 0)
+    torch.cuda.synchronize()
+    return d_ok.cpu().numpy().astype(np.uint32)[:count], failed, redone
