@@ -1081,6 +1081,34 @@ def main():
                                           stream, transcript=True)
             torch.cuda.synchronize()
             assert np.array_equal(d_ok_p.cpu().numpy().astype(np.int64), want_q), "production leg: status vector differs from the expected one"
+            # the same bytes through the grouped check behind the decoder: the same status words, timed on the valid batch;
+            # then the tampered batch must give the same exact status vector
+            grouped_p = None
+            if args.grouped_steps > 0:
+                gwsb_p = bv_p.serialized_grouped_workspace_bytes(pbatch, args.group)
+                d_gws_p = torch.empty(gwsb_p, dtype=torch.uint8, device=dev)
+                gkey_p = os.urandom(32)
+                gst_p = [None]
+
+                def pgstep(_i, blobs=d_bl_p):
+                    gst_p[0] = bv_p.verify_serialized_grouped_device(blobs.data_ptr(), d_cm_p.data_ptr(), pbatch, d_ok_p.data_ptr(),
+                                                                     d_gws_p.data_ptr(), gwsb_p, gkey_p, rank * pbatch, args.group,
+                                                                     stream, transcript=True)
+                d_ok_p.fill_(7)
+                pgstep(0)
+                pgdt = timed(pgstep, args.production_steps, torch, dist, coll_dev)
+                assert int(d_ok_p.cpu().numpy().sum()) == 0 and gst_p[0] == (0, 0), "production leg, grouped: a valid batch did not come back all Ok"
+                d_ok_p.fill_(7)
+                pgstep(0, d_bl_q)
+                torch.cuda.synchronize()
+                assert np.array_equal(d_ok_p.cpu().numpy().astype(np.int64), want_q), "production leg, grouped: status vector differs"
+                grouped_p = {"value": world * pbatch * args.production_steps / pgdt, "unit": "verifies/s",
+                             "ms_per_step": pgdt / args.production_steps * 1e3, "group": args.group,
+                             "status_check": {"tampered": int(Kq), "statuses_exact": True, "groups_failed": gst_p[0][0],
+                                              "proofs_reverified": gst_p[0][1]},
+                             "note": "bpp_range_verify_batch_serialized_grouped_device: decode + challenge derivation + one weighted "
+                                     "check per group of proofs, exact pass over the groups that fail; per-proof statuses"}
+                del d_gws_p
             ms_p = prdt / args.production_steps * 1e3
             derive_ms = ddt / args.production_steps * 1e3
             production["n=%d,m=%d" % (pn, pm)] = {
@@ -1090,6 +1118,7 @@ def main():
                 "stage_ms": {"decode": round(ms_p - sum(prst.values()) - derive_ms, 4), "derive_challenges": round(derive_ms, 4),
                              **{k: round(v, 4) for k, v in prst.items()}},
                 "status_check": {"tampered": int(Kq), "statuses_exact": True},
+                "grouped": grouped_p,
                 "roofline": verify_roofline("bls12_381", pn, pm, pbatch, pwin, prst["fixed_msm"], (a_p.PW - 1) // 2 * 8,
                                             launches=args.production_steps),
                 "note": "generators hashed from a label (bpp_pk_hashed), proofs made under the SHA-256 transcript with blinding from a "

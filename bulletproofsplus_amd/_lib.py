@@ -41,6 +41,7 @@ EXPORTS = [
     "bpp_proof_bytes_version", "bpp_proofs_encode_version",
     "bpp_range_verify_batch_serialized", "bpp_verifier_serialized_workspace_bytes",
     "bpp_range_verify_batch_serialized_device",
+    "bpp_verifier_serialized_grouped_workspace_bytes", "bpp_range_verify_batch_serialized_grouped_device",
 ]
 
 
@@ -136,6 +137,10 @@ def lib():
         L.bpp_verifier_serialized_workspace_bytes.argtypes = [vp, sz]
         L.bpp_verifier_serialized_workspace_bytes.restype = sz
         L.bpp_range_verify_batch_serialized_device.argtypes = [vp, vp, vp, sz, i32, vp, vp, sz, vp]
+        L.bpp_verifier_serialized_grouped_workspace_bytes.argtypes = [vp, sz, ctypes.c_uint32]
+        L.bpp_verifier_serialized_grouped_workspace_bytes.restype = sz
+        L.bpp_range_verify_batch_serialized_grouped_device.argtypes = [vp, vp, vp, sz, i32, ctypes.c_char_p, u64, ctypes.c_uint32,
+                                                                       vp, vp, vp, sz, vp]
         L.bpp_debug_field_op.argtypes = [vp, i32, i32, vp, vp, sz, vp]
         L.bpp_debug_point_op.argtypes = [vp, i32, vp, vp, sz, vp]
         _lib = L

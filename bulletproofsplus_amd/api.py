@@ -547,6 +547,28 @@ class BatchVerifier:
                                                                   workspace_bytes, stream or None),
               "bpp_range_verify_batch_serialized_device")
 
+    def serialized_grouped_workspace_bytes(self, count: int, group: int = 32) -> int:
+        return _lib.lib().bpp_verifier_serialized_grouped_workspace_bytes(self.handle, count, group)
+
+    def verify_serialized_grouped_device(self, d_proofs: int, d_commitments: int, count: int, d_ok: int, d_workspace: int,
+                                         workspace_bytes: int, weight_key: bytes = None, index_base: int = 0, group: int = 32,
+                                         stream: int = 0, transcript: bool = False, uncompressed: bool = False):
+        """verify_serialized_device with the grouped check behind the decoder (include/bpp_amd.h): the same status words at the
+        grouped check's price when (nearly) every proof is valid.  weight_key: 32 secret bytes, None = os.urandom(32).
+        Synchronises the stream.  -> (groups that failed, proofs re-verified exactly)"""
+        if weight_key is None:
+            import os
+            weight_key = os.urandom(32)
+        key = bytes(weight_key)
+        if len(key) != 32:
+            raise ValueError("weight_key must be 32 bytes")
+        stats = (ctypes.c_uint64 * 2)()
+        check(_lib.lib().bpp_range_verify_batch_serialized_grouped_device(
+            self.handle, d_proofs, d_commitments, count, (1 if transcript else 0) | (2 if uncompressed else 0), key,
+            ctypes.c_uint64(index_base), group, d_ok, stats, d_workspace, workspace_bytes, stream or None),
+            "bpp_range_verify_batch_serialized_grouped_device")
+        return int(stats[0]), int(stats[1])
+
     def run_device(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,
                    stream: int = 0, d_challenges: int = 0, d_out_scalars: int = 0, d_out_result: int = 0):
         check(_lib.lib().bpp_verifier_run(self.handle, d_points, d_scalars, count, d_challenges or None, d_ok,

@@ -828,6 +828,38 @@ extern "C" int bpp_range_verify_batch_serialized_device(bpp_verifier* v, const v
     });
 }
 
+// the same with the grouped check behind the decoder (per-proof statuses; synchronises the stream)
+extern "C" size_t bpp_verifier_serialized_grouped_workspace_bytes(const bpp_verifier* v, size_t count, uint32_t group) {
+    if (!v || group < 2 || (group & (group - 1))) return 0;
+    size_t r = 0;
+    dispatch(v->ctx.curve, [&](auto cv) -> int {
+        r = VerifyImpl<decltype(cv)>::ser_layout(v->s, count, group).total;
+        return 0;
+    });
+    return r;
+}
+extern "C" int bpp_range_verify_batch_serialized_grouped_device(bpp_verifier* v, const void* d_proofs, const void* d_commitments,
+                                                                size_t count, int flags, const uint8_t* weight_key,
+                                                                uint64_t index_base, uint32_t group, uint32_t* d_ok,
+                                                                uint64_t* stats, void* d_workspace, size_t workspace_bytes,
+                                                                void* stream) {
+    if (!v || !d_proofs || !d_commitments || !d_ok || !d_workspace || !weight_key) return fail(BPP_E_ARG, "null argument");
+    if (flags & ~(BPP_SER_TRANSCRIPT | BPP_SER_UNCOMPRESSED)) return fail(BPP_E_ARG, "unknown flag");
+    const int transcript = flags & BPP_SER_TRANSCRIPT;
+    const uint32_t version = (flags & BPP_SER_UNCOMPRESSED) ? 2u : 1u;
+    if (stats) stats[0] = stats[1] = 0;
+    if (count == 0) return BPP_OK;
+    if (count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count too large for one launch");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        using Impl = VerifyImpl<decltype(cv)>;
+        const typename Impl::GroupedArgs ga{weight_key, index_base, nullptr, group, stats};
+        return Impl::run_serialized(v, static_cast<const uint8_t*>(d_proofs), static_cast<const uint8_t*>(d_commitments), count,
+                                    transcript != 0, d_ok, d_workspace, workspace_bytes, static_cast<hipStream_t>(stream),
+                                    version, &ga);
+    });
+}
+
 // host buffers in, host verdicts out: the device path above between two copies
 extern "C" int bpp_range_verify_batch_serialized(bpp_verifier* v, const uint8_t* proofs, const uint8_t* commitments,
                                                  size_t count, int flags, uint32_t* out_ok) {

@@ -138,7 +138,8 @@ struct VerifyImpl {
     struct SerLayout {
         size_t records, scalars, status, challenges, run, total;
     };
-    static SerLayout ser_layout(const VerifyShape& s, size_t count) {
+    // group != 0: the verification behind the decoder is the grouped check (run_grouped) with groups of that size
+    static SerLayout ser_layout(const VerifyShape& s, size_t count, uint32_t group = 0) {
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         SerLayout w;
         size_t o = 0;
@@ -151,15 +152,24 @@ struct VerifyImpl {
         w.challenges = o;
         o += al(count * (size_t)(3 + s.k) * 32);
         w.run = o;
-        o += ws_layout(s, count).total;
+        o += group ? group_layout(s, count, group).total : ws_layout(s, count).total;
         w.total = o;
         return w;
     }
+    // the grouped check's arguments when it stands behind the decoder (run_serialized)
+    struct GroupedArgs {
+        const uint8_t* weight_key;
+        uint64_t index_base;
+        const uint64_t* d_weights;
+        uint32_t group;
+        uint64_t* h_stats;
+    };
     // d_proofs: count x container_bytes ; d_commitments: count x m compressed points ; d_ok: 0 Ok / 1 VerificationError /
     // 2 FormatError per proof.  Everything on `st`, no host synchronisation.
+    // grouped != null: verdicts through run_grouped (synchronises `st`)
     static int run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
                               bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes, hipStream_t st,
-                              uint32_t version = 1);
+                              uint32_t version = 1, const GroupedArgs* grouped = nullptr);
 
     // ---- combined batch check (combined.hpp) ------------------------------------------------------------
     struct CombLayout {
@@ -550,12 +560,12 @@ int VerifyImpl<C>::finish(bpp_verifier* v, uint8_t* ws, const WsLayout& L, size_
 template <class C>
 int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, const uint8_t* d_commitments, size_t count,
                                   bool transcript, uint32_t* d_ok, void* d_workspace, size_t workspace_bytes,
-                                  hipStream_t st, uint32_t version) {
+                                  hipStream_t st, uint32_t version, const GroupedArgs* grouped) {
     const VerifyShape& s = v->s;
     if (s.n > 255 || s.m > 255) return fail(BPP_E_ARG, "the container holds n, m <= 255");
     if (version != 1 && !(version == 2 && uncompressed_bytes<C>() != 0))
         return fail(BPP_E_ARG, "container version 2 (uncompressed points) is not offered for this curve");
-    const SerLayout L = ser_layout(s, count);
+    const SerLayout L = ser_layout(s, count, grouped ? grouped->group : 0u);
     if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
     uint8_t* ws = static_cast<uint8_t*>(d_workspace);
     uint32_t* w_rec = reinterpret_cast<uint32_t*>(ws + L.records);
@@ -573,8 +583,11 @@ int VerifyImpl<C>::run_serialized(bpp_verifier* v, const uint8_t* d_proofs, cons
         int rc = derive_challenges(v, reinterpret_cast<const uint64_t*>(w_rec), count, w_ch, st);
         if (rc) return rc;
     }
-    int rc = run(v, reinterpret_cast<const uint64_t*>(w_rec), reinterpret_cast<const uint64_t*>(w_sc), count,
-                 transcript ? w_ch : nullptr, d_ok, ws + L.run, workspace_bytes - L.run, nullptr, nullptr, st);
+    int rc = grouped ? run_grouped(v, reinterpret_cast<const uint64_t*>(w_rec), reinterpret_cast<const uint64_t*>(w_sc), count,
+                                   transcript ? w_ch : nullptr, grouped->weight_key, grouped->index_base, grouped->d_weights,
+                                   grouped->group, d_ok, grouped->h_stats, ws + L.run, workspace_bytes - L.run, st)
+                     : run(v, reinterpret_cast<const uint64_t*>(w_rec), reinterpret_cast<const uint64_t*>(w_sc), count,
+                           transcript ? w_ch : nullptr, d_ok, ws + L.run, workspace_bytes - L.run, nullptr, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_container_status<C>, dim3(cdiv(count, 256)), dim3(256), 0, st, w_st, d_ok, count);
     HIPCHK(hipGetLastError());

@@ -393,6 +393,15 @@ size_t bpp_verifier_serialized_workspace_bytes(const bpp_verifier *v, size_t cou
 int bpp_range_verify_batch_serialized_device(bpp_verifier *v, const void *d_proofs, const void *d_commitments, size_t count,
                                              int flags, uint32_t *d_ok, void *d_workspace, size_t workspace_bytes,
                                              void *stream);
+/* ... and with the grouped check (above) behind the decoder: the same status vector (0 / 1 / 2 per proof) at the grouped
+ * check's price when the batch is (nearly) all valid.  weight_key: 32 fresh secret bytes (host); index_base, group, stats as
+ * for bpp_verifier_run_grouped; the decoder's subgroup check provides the prime-order points the weighted check assumes.
+ * Synchronises `stream`.  d_workspace: bpp_verifier_serialized_grouped_workspace_bytes(v, count, group) bytes. */
+size_t bpp_verifier_serialized_grouped_workspace_bytes(const bpp_verifier *v, size_t count, uint32_t group);
+int bpp_range_verify_batch_serialized_grouped_device(bpp_verifier *v, const void *d_proofs, const void *d_commitments,
+                                                     size_t count, int flags, const uint8_t *weight_key, uint64_t index_base,
+                                                     uint32_t group, uint32_t *d_ok, uint64_t *stats, void *d_workspace,
+                                                     size_t workspace_bytes, void *stream);
 
 /* name of the kernel that dominates bpp_verifier_run (for profilers) and its launch geometry */
 const char *bpp_verifier_dominant_kernel(void);

@@ -142,3 +142,53 @@ def test_grouped_under_transcript_challenges():
     ok, failed, redone = run_grouped_device(torch, bv, recs, sc, 4)
     assert ok.tolist() == [1] * count and (failed, redone) == (3, 12)
     bv.close()
+
+
+@pytest.mark.parametrize("cname,transcript", [("bls12_381", False), ("bls12_381", True), ("ed25519", True)])
+def test_grouped_behind_the_decoder(cname, transcript):
+    """bpp_range_verify_batch_serialized_grouped_device: containers + compressed commitments in, status words 0 / 1 / 2 out,
+    equal to the per-proof serialized path's on valid, tampered and malformed input."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    n, m, count = 8, 2, 19
+    a = B.Arith.init(cname)
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=5)
+    vals = [[(13 * i + j) % 256 for j in range(m)] for i in range(count)]
+    gams = [[2 + i + 3 * j for j in range(m)] for i in range(count)]
+    pts, scs, V = bv.prove_batch(vals, gams, transcript=transcript)
+    blobs = B.encode_proofs(a, n, m, pts, scs)
+    comm = B.compress_points(a, V.reshape(-1, a.PW)).reshape(count, m, -1)
+    dev = torch.device("cuda:0")
+    d_cm = torch.from_numpy(np.ascontiguousarray(comm)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb = B.compressed_bytes(a)
+    sc0 = blobs.shape[1] - 96
+
+    def both(bl, group):
+        exact = bv.verify_serialized(bl, comm, transcript=transcript)
+        d_bl = torch.from_numpy(np.ascontiguousarray(bl)).to(dev)
+        d_ok = torch.full((count,), 7, dtype=torch.int32, device=dev)
+        wsb = bv.serialized_grouped_workspace_bytes(count, group)
+        d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        stats = bv.verify_serialized_grouped_device(d_bl.data_ptr(), d_cm.data_ptr(), count, d_ok.data_ptr(), d_ws.data_ptr(), wsb,
+                                                    None, 0, group, stream, transcript=transcript)
+        torch.cuda.synchronize()
+        return exact.tolist(), d_ok.cpu().numpy().astype(np.uint32).tolist(), stats
+
+    for group in (4, 8):
+        exact, got, stats = both(blobs, group)
+        assert exact == [0] * count and got == exact and stats == (0, 0)
+    bad = blobs.copy()
+    bad[1, sc0 + 3] ^= 4             # r': VerificationError
+    bad[6, 4] = 9                    # version byte: FormatError
+    bad[7, sc0 + 64 + 1] ^= 1        # delta'
+    bad[12, 12 + 2 * cb + 5] ^= 0x10  # wip.B: another point or no point at all
+    bad[18, sc0 + 32] ^= 1           # s' of the last proof (short group)
+    for group in (2, 4, 16):
+        exact, got, stats = both(bad, group)
+        assert got == exact, (group, exact, got)
+        assert exact[1] == 1 and exact[6] == 2 and exact[7] == 1 and exact[12] in (1, 2) and exact[18] == 1
+        assert sum(1 for x in exact if x) == 5
+        assert 1 <= stats[0] <= 5
+    bv.close()
