@@ -507,8 +507,33 @@ def main():
             lst, _, _ = bv.profile()
             bv.set_profiling(False)
             assert int(d_ok[:Bl].sum().item()) == 0
+            # the round trip a caller waits for -- enqueue, then synchronise, one pass at a time -- eagerly and as a replay
+            # of the pass captured into a HIP graph by the library (bpp_verifier_graph_capture)
+            def round_trip(fn):
+                best = 1e9
+                for _ in range(max(3, args.latency_steps)):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    best = min(best, time.perf_counter() - t0)
+                return best * 1e3
+            rt = round_trip(lambda: bv.run_device(d_pts.data_ptr(), d_sc.data_ptr(), Bl, d_ok.data_ptr(), d_ws.data_ptr(),
+                                                  max(wl, 1), stream))
+            pg = bv.graph_capture(d_pts.data_ptr(), d_sc.data_ptr(), Bl, d_ok.data_ptr(), d_ws.data_ptr(), max(wl, 1))
+            d_ok[:Bl].fill_(7)
+            pg.launch(stream)
+            torch.cuda.synchronize()
+            assert int(d_ok[:Bl].sum().item()) == 0, "latency leg: the replayed graph gave other verdicts"
+            rt_g = round_trip(lambda: pg.launch(stream))
+            dg = timed(lambda i: pg.launch(stream), args.latency_steps, torch, None, dev)
+            pg.close()
             latency["B=%d" % Bl] = {"ms": dl / args.latency_steps * 1e3, "verifies_per_s": Bl * args.latency_steps / dl,
-                                    "stage_ms": {k: round(v, 4) for k, v in lst.items()}}
+                                    "stage_ms": {k: round(v, 4) for k, v in lst.items()},
+                                    "graph_ms": dg / args.latency_steps * 1e3,
+                                    "round_trip_ms": {"eager": rt, "graph_replay": rt_g,
+                                                      "note": "wall clock of enqueue + synchronise of ONE pass (best of %d); `ms` "
+                                                              "and `graph_ms` are passes enqueued back to back" % max(3, args.latency_steps)}}
 
     # ---- the batched prover with every buffer in HBM ---------------------------
     prove = None

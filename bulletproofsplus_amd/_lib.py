@@ -31,7 +31,7 @@ EXPORTS = [
     "bpp_scalar_mul_batch", "bpp_pk_new", "bpp_pk_hashed", "bpp_commit", "bpp_range_prove", "bpp_range_prove_batch", "bpp_range_verify", "bpp_set_verify_cache", "bpp_wip_fold_round",
     "bpp_prover_workspace_bytes", "bpp_range_prove_batch_device",
     "bpp_verifier_create", "bpp_verifier_destroy", "bpp_verifier_workspace_bytes", "bpp_verifier_msm_len",
-    "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
+    "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_verifier_graph_capture", "bpp_graph_launch", "bpp_graph_destroy", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
     "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_set_subgroup_check", "bpp_verifier_partial_bytes",
     "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
     "bpp_verifier_grouped_workspace_bytes", "bpp_verifier_run_grouped",
@@ -101,6 +101,10 @@ def lib():
         L.bpp_verifier_table_bytes.restype = sz
         L.bpp_verifier_run.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, vp, vp, vp]
         L.bpp_range_verify_batch.argtypes = [vp, vp, vp, sz, vp]
+        L.bpp_verifier_graph_capture.argtypes = [vp, vp, vp, sz, vp, vp, vp, sz, ctypes.POINTER(vp)]
+        L.bpp_graph_launch.argtypes = [vp, vp]
+        L.bpp_graph_destroy.argtypes = [vp]
+        L.bpp_graph_destroy.restype = None
         L.bpp_verifier_dominant_kernel.restype = ctypes.c_char_p
         L.bpp_verifier_set_profiling.argtypes = [vp, i32]
         L.bpp_verifier_set_subgroup_check.argtypes = [vp, i32]

@@ -576,6 +576,36 @@ class BatchVerifier:
                                           stream or None), "bpp_verifier_run")
 
 
+class PassGraph:
+    """One pass of the batch verifier captured into a HIP graph (bpp_verifier_graph_capture): launch() replays it over the
+    buffers it was captured with.  Keep the verifier alive while its graphs are."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def launch(self, stream: int = 0):
+        check(_lib.lib().bpp_graph_launch(self.handle, stream or None), "bpp_graph_launch")
+
+    def close(self):
+        if self.handle:
+            _lib.lib().bpp_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _verifier_graph_capture(self, d_points: int, d_scalars: int, count: int, d_ok: int, d_workspace: int, workspace_bytes: int,
+                            d_challenges: int = 0) -> PassGraph:
+    h = ctypes.c_void_p()
+    check(_lib.lib().bpp_verifier_graph_capture(self.handle, d_points, d_scalars, count, d_challenges or None, d_ok, d_workspace,
+                                                workspace_bytes, ctypes.byref(h)), "bpp_verifier_graph_capture")
+    return PassGraph(h)
+
+
 STAGES = ("from_wire", "verify_scalars", "fixed_msm", "var_msm", "finalize")
 
 
@@ -733,6 +763,7 @@ def _verifier_set_subgroup_check(self, on: bool):
 
 
 BatchVerifier.set_subgroup_check = _verifier_set_subgroup_check
+BatchVerifier.graph_capture = _verifier_graph_capture
 BatchVerifier.set_profiling = _verifier_set_profiling
 BatchVerifier.profile = _verifier_profile
 

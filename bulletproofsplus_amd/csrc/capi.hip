@@ -360,6 +360,65 @@ extern "C" int bpp_verifier_run(bpp_verifier* v, const uint64_t* d_points, const
     });
 }
 
+// ---- one pass as a HIP graph: captured once, replayed over the same buffers -----------------------------------
+struct bpp_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int device = 0;
+};
+extern "C" void bpp_graph_destroy(bpp_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+extern "C" int bpp_verifier_graph_capture(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                          const uint64_t* d_challenges, uint32_t* d_ok, void* d_workspace,
+                                          size_t workspace_bytes, bpp_graph** out) {
+    if (!v || !d_points || !d_scalars || !d_ok || !d_workspace || !out) return fail(BPP_E_ARG, "null argument");
+    if (count == 0 || count > 0x7fffffffu / 64) return fail(BPP_E_ARG, "count out of range");
+    if (v->profiling) return fail(BPP_E_ARG, "switch the stage profiling off before capturing a pass");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    hipStream_t cs = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    auto pass = [&]() {
+        return dispatch(v->ctx.curve, [&](auto cv) -> int {
+            return VerifyImpl<decltype(cv)>::run(v, d_points, d_scalars, count, d_challenges, d_ok, d_workspace, workspace_bytes,
+                                                 nullptr, nullptr, cs);
+        });
+    };
+    // one eager pass first: it checks the arguments and creates what a pass creates lazily (the side stream and its events
+    // of a lone batch), which must not happen inside a capture
+    int rc = pass();
+    hipError_t e = rc ? hipSuccess : hipStreamSynchronize(cs);
+    if (rc || e != hipSuccess) {
+        (void)hipStreamDestroy(cs);
+        return rc ? rc : fail(BPP_E_HIP, std::string("eager pass before the capture failed: ") + hipGetErrorString(e));
+    }
+    bpp_graph* g = new bpp_graph();
+    g->device = v->ctx.device;
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+        rc = pass();
+        const hipError_t e2 = hipStreamEndCapture(cs, &g->graph);   // always ends the capture, also after a failed pass
+        if (!rc) e = e2;
+    }
+    if (!rc && e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    (void)hipStreamDestroy(cs);
+    if (rc || e != hipSuccess) {
+        bpp_graph_destroy(g);
+        return rc ? rc : fail(BPP_E_HIP, std::string("graph capture failed: ") + hipGetErrorString(e));
+    }
+    *out = g;
+    return BPP_OK;
+}
+extern "C" int bpp_graph_launch(bpp_graph* g, void* stream) {
+    if (!g || !g->exec) return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+    return BPP_OK;
+}
+
 extern "C" int bpp_range_prove_batch(bpp_verifier* engine, const uint64_t* v, const uint64_t* gamma, size_t count,
                                      uint64_t* out_points, uint64_t* out_scalars, uint64_t* out_V) {
     if (!engine || !v || !gamma || !out_points || !out_scalars) return fail(BPP_E_ARG, "null argument");

@@ -197,6 +197,18 @@ int bpp_verifier_run(bpp_verifier *v, const uint64_t *d_points, const uint64_t *
                      const uint64_t *d_challenges, uint32_t *d_ok, void *d_workspace,
                      size_t workspace_bytes, uint64_t *d_out_scalars, uint64_t *d_out_result,
                      void *stream);
+/* The same pass captured ONCE into a HIP graph and replayed: a small batch is a chain of a dozen launches and a stream
+ * fork/join that a replay submits in one call.  bpp_verifier_graph_capture runs the pass once eagerly (argument checks;
+ * what a pass creates lazily must exist before a capture), captures it on a stream of its own and instantiates the graph;
+ * the device pointers and `count` are baked in: the caller refreshes the CONTENTS of d_points / d_scalars / d_challenges
+ * between replays and reads d_ok after them.  bpp_graph_launch only enqueues (hipGraphLaunch on `stream`).  The verifier must
+ * outlive its graphs; stage profiling must be off while capturing. */
+typedef struct bpp_graph bpp_graph;
+int bpp_verifier_graph_capture(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                               const uint64_t *d_challenges, uint32_t *d_ok, void *d_workspace, size_t workspace_bytes,
+                               bpp_graph **out);
+int bpp_graph_launch(bpp_graph *g, void *stream);
+void bpp_graph_destroy(bpp_graph *g);
 
 /* RangeProof::prove for `count` independent provers that share (pk, n, m) -- and RangeProver::commit for
  * their values -- in one device-resident pass (csrc/prover_batch.hpp): the folding rounds of

@@ -264,3 +264,47 @@ def test_two_verifiers_coresident_interleaved():
         want[bad] = 1
         assert np.array_equal(ok, want), name
         eng[name].close()
+
+
+@pytest.mark.parametrize("count", [1, 5, 300])
+def test_native_pass_graph_replays(count):
+    """bpp_verifier_graph_capture / bpp_graph_launch: the pass captured by the library itself (no PyTorch capture in between);
+    replays follow the contents of the captured buffers, on the caller's stream."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    n, m = 8, 2
+    a = B.Arith.init("bls12_381")
+    pk = B.PublicKey.new(a, n * m)
+    bv = B.BatchVerifier(pk, n, m, window_bits=5)
+    vals = [[(11 * i + j) % 256 for j in range(m)] for i in range(count)]
+    gams = [[1 + i + 2 * j for j in range(m)] for i in range(count)]
+    pts, scs, V = bv.prove_batch(vals, gams)
+    recs = np.ascontiguousarray(np.concatenate([pts, V], axis=1))
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(recs.view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(np.ascontiguousarray(scs).view(np.int64)).to(dev)
+    d_ok = torch.full((count,), 7, dtype=torch.int32, device=dev)
+    wsb = bv.workspace_bytes(count)
+    d_ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    g = bv.graph_capture(d_pts.data_ptr(), d_sc.data_ptr(), count, d_ok.data_ptr(), d_ws.data_ptr(), wsb)
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep in range(3):
+        d_ok.fill_(7)
+        g.launch(stream)
+        torch.cuda.synchronize()
+        assert d_ok.cpu().numpy().tolist() == [0] * count
+    bad = scs.copy()
+    bad[count // 2, 1, 0] ^= np.uint64(2)
+    d_sc.copy_(torch.from_numpy(np.ascontiguousarray(bad).view(np.int64)))
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g.launch(s2.cuda_stream)
+    s2.synchronize()
+    assert d_ok.cpu().numpy().tolist() == [1 if i == count // 2 else 0 for i in range(count)]
+    bv.set_profiling(True)
+    with pytest.raises(B.BppError):
+        bv.graph_capture(d_pts.data_ptr(), d_sc.data_ptr(), count, d_ok.data_ptr(), d_ws.data_ptr(), wsb)
+    bv.set_profiling(False)
+    g.close()
+    bv.close()

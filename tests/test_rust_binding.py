@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import gen_rust_ffi as G  # noqa: E402
 
 RUST_SCALAR = {"c_int": "int", "usize": "size_t", "u64": "uint64_t", "u32": "uint32_t", "u8": "uint8_t", "c_uint": "unsigned",
-               "f32": "float", "c_char": "char", "c_void": "void", "BppCtx": "bpp_ctx", "BppVerifier": "bpp_verifier"}
+               "f32": "float", "c_char": "char", "c_void": "void", "BppCtx": "bpp_ctx", "BppVerifier": "bpp_verifier", "BppGraph": "bpp_graph"}
 
 
 def rust_prototypes(text):
