@@ -91,6 +91,7 @@ struct PipShape {
 // max_words: the largest sub-scalar value (8 words); bits: its bit length
 inline int pip_shape(size_t n, int c, bool glv, const uint32_t* max_words, int bits, PipShape& s) {
     if (c < 2 || c > 16) return fail(BPP_E_ARG, "window_bits must be in [2, 16]");
+    if (n >= ((size_t)1 << 28)) return fail(BPP_E_ARG, "MulVec too long for one call");   // a sorted entry is item << 1 | sign, bit 31 a flag
     s.n = (uint32_t)n;
     s.glv = glv ? 1u : 0u;
     s.items = (uint32_t)(glv ? 2 * n : n);
@@ -415,6 +416,9 @@ __global__ void __launch_bounds__(256) k_pip_place(PipShape s, const uint32_t* _
 }
 
 // one block per (window, coarse bin): the bin's records -> bucket order.  counts / offsets: flat per bucket.
+// A sorted entry is  item << 1 | sign  with PIP_LAST set on the last entry of every bucket: k_pip_chunks then knows where a
+// bucket ends without looking anything up.
+constexpr uint32_t PIP_LAST = 0x80000000u;
 template <class C>
 __global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const uint32_t* __restrict__ ccount,
                                                           const uint32_t* __restrict__ cstart,
@@ -480,7 +484,10 @@ __global__ void __launch_bounds__(PIP_FINE_MAX) k_pip_binsort(PipShape s, const 
         }
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (lw[u] != 0xffffffffu) so[atomicAdd(&cnt[lw[u]], 1u)] = it[u];
+            if (lw[u] != 0xffffffffu) {   // bit 31: the last entry of its bucket (pre[] = one past it)
+                const uint32_t pos = atomicAdd(&cnt[lw[u]], 1u);
+                so[pos] = it[u] | (pos + 1 == pre[lw[u]] ? PIP_LAST : 0u);
+            }
     }
 }
 
@@ -521,30 +528,55 @@ __global__ void __launch_bounds__(1024) k_pip_segments(PipShape s, const uint32_
 }
 
 // ---- bucket sums, chunk by chunk ------------------------------------------------------------------------------
-// One lane per (window, chunk of L sorted entries): an XYZZ running sum over the chunk, flushed as a jacobian into the
-// segment slot of (bucket, chunk) whenever the bucket changes and at the chunk's end.  The points are gathered by
-// LDS-DMA (glds16, kernels.hpp) into a two-deep per-lane ring, one addition ahead, exactly as k_fixed_msm gathers its
-// table entries: all lanes of a wave step together, a lane past its last entry DMAs a dummy line, and a counted
-// s_waitcnt vmcnt is all the synchronisation the ring needs (any further VMEM operation in flight -- the bucket
-// bookkeeping, a flush -- only makes the count more conservative).  The sorted entries themselves travel the same way,
-// four per lane per DMA, one batch ahead: a plain load of the next entry inside the loop made the compiler wait for
-// EVERYTHING in flight -- the point just requested included -- before every step.
+// One lane per (window, chunk of L sorted entries): an XYZZ running sum over the chunk, written into the next segment slot
+// whenever a bucket ends (PIP_LAST of the entry) and at the chunk's end.  The slots of a window are numbered in the order the
+// segments appear -- bucket by bucket, and inside a bucket chunk by chunk: slot(b, k) = segbase[b] + (k - first chunk of b) --
+// so after a bucket's last entry the lane's next segment is simply the next slot, and nothing is looked up inside the loop.
+// A segment is the RAW accumulator (four coordinates, unpacked 30-bit limbs, not reduced): converting it to the jacobian
+// form costs two products, and inside this loop a whole wave pays them whenever ONE of its lanes meets a bucket boundary
+// (a quarter to two thirds of the steps); k_pip_fold pays them once per segment, every lane busy.
+// The points are gathered by LDS-DMA (glds16, kernels.hpp) into a two-deep per-lane ring, one addition ahead, exactly as
+// k_fixed_msm gathers its table entries: all lanes of a wave step together, a lane past its last entry DMAs a dummy line,
+// and a counted s_waitcnt vmcnt is all the synchronisation the ring needs (a flush's stores in flight only make the count
+// more conservative).  The sorted entries themselves travel the same way, four per lane per DMA, one batch ahead.
 constexpr unsigned PIP_BLOCK = 128;
 template <class C>
 constexpr unsigned pip_ring_bytes() {
     return (PIP_BLOCK / 64) * (2 * (2 * C::Fp::N / 4) + 2) * 1024;   // two point slots + two slots of four sorted entries per lane
 }
+// words of a segment: the accumulator as it is in registers
+template <class C>
+constexpr int seg_words() {
+    return (int)(sizeof(Xyzz<C>) / 4);
+}
+template <class C>
+__device__ __forceinline__ void seg_stg(uint32_t* __restrict__ p, const Xyzz<C>& a) {
+    struct Raw {
+        uint32_t w[seg_words<C>()];
+    };
+    const Raw r = __builtin_bit_cast(Raw, a);
+    st_words<seg_words<C>()>(p, r.w);
+}
+template <class C>
+__device__ __forceinline__ Jac<C> seg_ldg(const uint32_t* __restrict__ p) {
+    struct Raw {
+        uint32_t w[seg_words<C>()];
+    };
+    Raw r;
+    ld_words<seg_words<C>()>(p, r.w);
+    return xyzz_to_jac(__builtin_bit_cast(Xyzz<C>, r));
+}
 template <class C>
 __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipShape s, const uint32_t* __restrict__ points,
                                                         const uint32_t* __restrict__ sorted,
                                                         const uint32_t* __restrict__ offsets,
-                                                        const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ segbase,
                                                         const uint32_t* __restrict__ chunk_first,
                                                         const uint32_t* __restrict__ wtotal,
                                                         uint32_t* __restrict__ segs) {
     constexpr int N = C::Fp::N;
-    constexpr int JW = jac_words<C>();
+    constexpr int SW = seg_words<C>();
+    static_assert(SW % 4 == 0, "segments are written in 16-byte pieces");
     constexpr int CH = 2 * N / 4;                 // 16-byte pieces of a point
     constexpr int WAVE_WORDS = (2 * CH + 2) * 256;   // LDS words of one wave: the point ring + two batches of sorted entries
     extern __shared__ __align__(16) uint32_t lds[];
@@ -560,16 +592,12 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
     const uint32_t ring_addr = (uint32_t)reinterpret_cast<uintptr_t>(ring);
     const uint32_t ebuf_addr = ring_addr + 2 * CH * 1024;
     const uint32_t* row = sorted + (size_t)j * s.istride;
-    const uint32_t bb = s.bbase(j);
     const uint32_t pos0 = (uint64_t)k * s.L < total ? k * s.L : total;
     const uint32_t stop = min(pos0 + s.L, total);           // pos0 >= stop: a lane without entries
-    uint32_t b = 0, bend = 0;
     uint32_t* seg = segs;
     if (pos0 < stop) {
-        b = chunk_first[(size_t)j * s.cpw + k];
-        const uint32_t o = offsets[bb + b];
-        bend = o + counts[bb + b];
-        seg = segs + ((size_t)j * s.capseg + segbase[bb + b] + (k - o / s.L)) * JW;
+        const uint32_t b = s.bbase(j) + chunk_first[(size_t)j * s.cpw + k];
+        seg = segs + ((size_t)j * s.capseg + segbase[b] + (k - offsets[b] / s.L)) * SW;
     }
     // batch q = this lane's entries 4 q .. 4 q + 3 (16 bytes, 16-byte aligned: pos0 is a multiple of L >= 8 and rows start
     // aligned) -> entry slot q & 1.  A batch is requested four steps before its first entry is needed.
@@ -578,22 +606,24 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous batch has been read out
         glds16(row + (p < stop ? p : 0), ebuf_addr + (q & 1u) * 1024);
     };
-    uint32_t nbits = 0;
+    uint32_t nbits = 0, lbits = 0;   // sign / last-of-bucket flag of the entries in the two ring slots
     auto issue = [&](uint32_t t) {
         const uint32_t slot = t & 1u;
         const uint32_t p = pos0 + t;
         if ((t & 3u) == 0) dma_entries((t >> 2) + 1);
         const uint32_t e = ebuf[((t >> 2) & 1u) * 256 + lane * 4 + (t & 3u)];
         const uint32_t* src = points;   // dummy line
-        uint32_t neg = 0;
+        uint32_t neg = 0, last = 0;
         if (p < stop) {
-            src = points + (size_t)(e >> 1) * 2 * N;
+            src = points + (size_t)((e & ~PIP_LAST) >> 1) * 2 * N;
             neg = e & 1u;
+            last = e >> 31;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's previous point has been read out
 #pragma unroll
         for (int kk = 0; kk < CH; kk++) glds16(src + 4 * kk, ring_addr + (slot * CH + kk) * 1024);
         nbits = (nbits & ~(1u << slot)) | (neg << slot);
+        lbits = (lbits & ~(1u << slot)) | (last << slot);
     };
     dma_entries(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -615,23 +645,16 @@ __global__ void __launch_bounds__(PIP_BLOCK, fixed_waves<C>()) k_pip_chunks(PipS
             raw[4 * kk + 3] = v.w;
         }
         const bool neg = (nbits >> slot) & 1u;
+        const bool last = (lbits >> slot) & 1u;
         const Aff<C> cur = aff_load<C>(raw);
         issue(t + 2);
         const uint32_t p = pos0 + t;
         if (p < stop) {
             xyzz_madd_lazy(acc, cur, neg);
-            if (p + 1 == bend || p + 1 == stop) {   // the bucket's last entry, or the chunk's
-                jac_stg<C>(seg, xyzz_to_jac(acc));
+            if (last || p + 1 == stop) {   // the bucket's last entry, or the chunk's: on to the next slot
+                seg_stg<C>(seg, acc);
+                seg += SW;
                 acc = xyzz_inf<C>();
-                if (p + 1 < stop) {   // on to the next non-empty bucket: it starts inside this chunk (segment 0 of it)
-                    uint32_t cnt;
-                    do {
-                        b++;
-                        cnt = counts[bb + b];
-                    } while (cnt == 0);
-                    bend = p + 1 + cnt;
-                    seg = segs + ((size_t)j * s.capseg + segbase[bb + b]) * JW;
-                }
             }
         }
     }
@@ -663,8 +686,8 @@ __global__ void __launch_bounds__(128) k_pip_fold(PipShape s, const uint32_t* __
             // window of the bucket: the wide windows come first
             const uint32_t wide = s.nwide << s.q;
             const uint32_t j = gid < wide ? gid >> s.q : min(s.nwide + ((gid - wide) >> (s.q - 1)), s.W - 1);
-            const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * JW;
-            for (uint32_t t = sub; t < nseg; t += s.fl) acc = jac_add(acc, jac_ldg<C>(sp + (size_t)t * JW));
+            const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * seg_words<C>();
+            for (uint32_t t = sub; t < nseg; t += s.fl) acc = jac_add(acc, seg_ldg<C>(sp + (size_t)t * seg_words<C>()));
         }
     }
     if (s.fl > 1) acc = wave_sum_jac<C>(acc, (int)s.fl);   // every lane of the wave takes part
@@ -687,9 +710,9 @@ __global__ void __launch_bounds__(64) k_pip_fold_heavy(PipShape s, const uint32_
         const uint32_t nseg = (o + cnt - 1) / s.L - o / s.L + 1;
         const uint32_t wide = s.nwide << s.q;
         const uint32_t j = gid < wide ? gid >> s.q : min(s.nwide + ((gid - wide) >> (s.q - 1)), s.W - 1);
-        const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * JW;
+        const uint32_t* sp = segs + ((size_t)j * s.capseg + segbase[gid]) * seg_words<C>();
         Jac<C> acc = jac_inf<C>();
-        for (uint32_t t = lane; t < nseg; t += 64) acc = jac_add(acc, jac_ldg<C>(sp + (size_t)t * JW));
+        for (uint32_t t = lane; t < nseg; t += 64) acc = jac_add(acc, seg_ldg<C>(sp + (size_t)t * seg_words<C>()));
         acc = wave_sum_jac<C>(acc);
         if (lane == 0) jac_stg<C>(buckets + (size_t)gid * JW, acc);
     }
@@ -856,7 +879,7 @@ inline PipWorkspace pip_workspace(const PipShape& s) {
     w.wtotal = o;
     o += al((size_t)s.W * 4);
     w.segs = o;
-    o += al((size_t)s.W * s.capseg * JW * 4);
+    o += al((size_t)s.W * s.capseg * seg_words<C>() * 4);
     w.buckets = o;
     o += al((size_t)s.nbuckets * JW * 4);
     w.tiles = o;
@@ -913,7 +936,7 @@ inline hipError_t pip_launch(const PipShape& s, const uint32_t* d_scalars, const
     mark(1);
     const uint32_t bpw = (s.cpw + PIP_BLOCK - 1) / PIP_BLOCK;
     hipLaunchKernelGGL(k_pip_chunks<C>, dim3(s.W * bpw), dim3(PIP_BLOCK), pip_ring_bytes<C>(), st, s, points, sorted,
-                       offsets, counts, segbase, chunk_first, wtotal, segs);
+                       offsets, segbase, chunk_first, wtotal, segs);
     mark(2);
     hipLaunchKernelGGL(k_pip_fold<C>, dim3((unsigned)(((size_t)s.nbuckets * s.fl + 127) / 128)), dim3(128), 0, st, s, offsets, counts, segbase, segs,
                        buckets, hlist, hcount);
