@@ -6,6 +6,8 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# BPP_HOST_SANITIZE=1: host builds under ASan + UBSan (see tests/test_host_arith_cpu.py)
+SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("BPP_HOST_SANITIZE") else []
 
 
 def test_library_exports_every_declared_symbol():
@@ -49,7 +51,7 @@ def test_host_field_arithmetic_matches_bigints():
     import tempfile
     import pyref as P
     exe = os.path.join(tempfile.gettempdir(), "bpp_field_host_test")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "field_host_test.cpp")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17"] + SANITIZE + ["-o", exe, os.path.join(ROOT, "tests", "host", "field_host_test.cpp")])
     mods = {"blsfp": P.BLS12_381["p"], "blsfr": P.BLS12_381["r"], "secpfp": P.SECP256K1["p"], "secpfr": P.SECP256K1["r"],
             "edfp": P.ED25519["p"], "edfr": P.ED25519["r"]}
     rnd = random.Random(3)

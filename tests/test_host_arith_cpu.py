@@ -13,9 +13,14 @@ import pyref as P
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# BPP_HOST_SANITIZE=1: the same host builds under AddressSanitizer + UndefinedBehaviorSanitizer (the GPU pool offers no
+# sanitizer, so the device headers' arithmetic gets its sanitizer run here, on the CPU build)
+SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("BPP_HOST_SANITIZE") else []
+
+
 def _build(name, opt="-O1"):
-    exe = os.path.join(tempfile.gettempdir(), "bpp_" + name)
-    subprocess.check_call(["g++", opt, "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", name + ".cpp")])
+    exe = os.path.join(tempfile.gettempdir(), "bpp_" + name + ("_san" if SANITIZE else ""))
+    subprocess.check_call(["g++", opt, "-std=c++17"] + SANITIZE + ["-o", exe, os.path.join(ROOT, "tests", "host", name + ".cpp")])
     return exe
 
 

@@ -14,12 +14,14 @@ import pytest
 import pyref as P
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# BPP_HOST_SANITIZE=1: host builds under ASan + UBSan (see tests/test_host_arith_cpu.py)
+SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("BPP_HOST_SANITIZE") else []
 
 
 @pytest.fixture(scope="module")
 def harness():
     exe = os.path.join(tempfile.gettempdir(), "bpp_transcript_host_test")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "transcript_host_test.cpp")])
+    subprocess.check_call(["g++", "-O2", "-std=c++17"] + SANITIZE + ["-o", exe, os.path.join(ROOT, "tests", "host", "transcript_host_test.cpp")])
     return exe
 
 
