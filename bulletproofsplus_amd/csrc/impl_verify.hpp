@@ -276,7 +276,11 @@ struct VerifyImpl {
         w.x_ok = o;
         o += al(w.slice * 4);
         w.x_run = o;
-        o += ws_layout(s, w.slice).total;
+        // the exact pass runs over however many proofs the failing groups hold, and a SMALLER batch can need a LARGER
+        // workspace (more blocks per proof, blocks_per_proof): room for the worst count up to the slice
+        size_t xrun = 0;
+        for (size_t c = 1; c <= w.slice; c++) xrun = std::max(xrun, ws_layout(s, c).total);
+        o += xrun;
         w.total = o;
         return w;
     }

@@ -192,3 +192,29 @@ def test_grouped_behind_the_decoder(cname, transcript):
         assert sum(1 for x in exact if x) == 5
         assert 1 <= stats[0] <= 5
     bv.close()
+
+
+def test_grouped_exact_pass_fits_whatever_the_failing_count():
+    """A smaller exact pass can need a LARGER workspace than a full slice (more blocks per proof for fewer proofs): the
+    grouped workspace must hold the worst count.  (64,1) x 4096 with 47 failing groups = 1 504 proofs re-verified hit it."""
+    torch = need_gpu()
+    import bulletproofsplus_amd as B
+    n, m, count, group = 64, 1, 4096, 32
+    a = B.Arith.init("bls12_381")
+    bv = B.BatchVerifier(B.PublicKey.new(a, n * m), n, m, window_bits=6)
+    vals = [[(0x1234567 * (i + 1)) % (1 << 31)] for i in range(8)]   # below 2^31: the reference's `v as i32` (range/mod.rs)
+    gams = [[3 + i] for i in range(8)]
+    pts, scs, V = bv.prove_batch(vals, gams)
+    recs8 = np.concatenate([pts, V], axis=1)
+    idx = np.arange(count) % 8
+    recs, sc = np.ascontiguousarray(recs8[idx]), np.ascontiguousarray(scs[idx])
+    for ngroups in (47, 1, 64):
+        bad = sc.copy()
+        victims = [g * group + (7 * g) % group for g in range(0, 2 * ngroups, 2)]
+        for v in victims:
+            bad[v, 1, 0] ^= np.uint64(1)
+        ok, failed, redone = run_grouped_device(torch, bv, recs, bad, group, seed=ngroups)
+        want = np.zeros(count, dtype=np.uint32)
+        want[victims] = 1
+        assert np.array_equal(ok, want) and (failed, redone) == (ngroups, ngroups * group)
+    bv.close()
