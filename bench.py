@@ -914,10 +914,16 @@ def main():
                             d_challenges=d_ch.data_ptr())
 
         hstep(0)
+        bv_h.set_profiling(True)
         hdt = timed(hstep, args.hard_steps, torch, dist, coll_dev)
+        hst, _, _ = bv_h.profile()
+        bv_h.set_profiling(False)
         rejected = int((d_ok != 0).sum().item())
         hard = {"value": world * Bsz * args.hard_steps / hdt, "unit": "verifies/s", "steps": args.hard_steps,
                 "ms_per_step": hdt / args.hard_steps * 1e3, "rejected_under_random_challenges": rejected,
+                "stage_ms": {k: round(v, 4) for k, v in hst.items()},
+                "roofline": verify_roofline(args.curve, n, m, Bsz, args.window, hst["fixed_msm"], (a.PW - 1) // 2 * 8,
+                                            launches=args.hard_steps),
                 "note": "random generators k_i*g (SplitMix64) and per-proof uniformly random full-width challenges (y, z, e, e_1..e_k) "
                         "through d_challenges: every MulVec scalar is full width; the proofs were made for the default "
                         "challenges, so they are rejected here -- the pass does the same work for valid and invalid proofs"}
