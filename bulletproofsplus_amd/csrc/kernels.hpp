@@ -1029,8 +1029,8 @@ struct VpSel {
 // DMAs a dummy line -- so every step issues exactly 2N/4 DMA instructions per wave and a counted
 // s_waitcnt vmcnt((FIXED_RING-1) * 2N/4) is all the synchronisation the ring needs.  The next generator's
 // scalar travels the same way (2 pieces), one generator ahead.
-// waves per SIMD the register allocator must leave room for: two for the 13-limb field (219 VGPRs), three for the 9-limb
-// fields (158 / 145 VGPRs fit the 170 of a three-wave budget)
+// waves per SIMD the register allocator must leave room for: two for the 13-limb field (201 VGPRs), three for the 9-limb
+// fields (152 / 164 VGPRs fit the 170 of a three-wave budget; tools/kernel_resources.py prints the current numbers)
 template <class C>
 constexpr int fixed_waves() {
     return C::Fp::NL > 9 ? BPP_FIXED_WAVES : 3;
