@@ -8,7 +8,7 @@ OUT=$(readlink -f "$1"); PART=${2:-all}
 mkdir -p "$OUT"
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-OFF="--c3-steps 0 --prove-steps 0 --serialized-steps 0 --hard-steps 0 --other-curves-steps 0 --production-steps 0 --single-call-reps 0 --msm-steps 0 --latency-steps 0 --combined-steps 0 --grouped-steps 0 --cpu-seconds 0"
+OFF="--c3-steps 0 --prove-steps 0 --serialized-steps 0 --hard-steps 0 --other-curves-steps 0 --production-steps 0 --single-call-reps 0 --msm-steps 0 --latency-steps 0 --combined-steps 0 --grouped-steps 0 --pipeline-streams 0 --cpu-seconds 0"
 prof() {  # name, bench args...
     local name=$1; shift
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -o k -- python3 "$ROOT/bench.py" "$@" > "$OUT/$name.json" 2> "$OUT/$name.err" || return 1
@@ -18,6 +18,7 @@ if [ "$PART" = all ] || [ "$PART" = 1 ]; then
     prof headline $OFF || exit 1                      # k_fixed_msm<..., 0>: only launches at the bench geometry
     prof latency_combined $OFF --latency-steps 5 --combined-steps 10 || exit 1
     prof grouped $OFF --grouped-steps 5 || exit 1
+    prof pipelined $OFF --pipeline-streams 2 || exit 1
     prof c3 --config c3 $OFF --combined-steps 5 || exit 1
     prof prove_serialized_production $OFF --prove-steps 2 --serialized-steps 3 --production-steps 3 || exit 1
     prof msm $OFF --steps 2 --warmup 1 --msm-steps 5 || exit 1

@@ -16,7 +16,7 @@ def last_json(path):
     return json.loads([l for l in open(path).read().strip().splitlines() if l.startswith("{")][-1])
 
 
-for leg in ("headline", "latency_combined", "grouped", "c3", "prove_serialized_production", "msm"):
+for leg in ("headline", "latency_combined", "grouped", "pipelined", "c3", "prove_serialized_production", "msm"):
     if not os.path.exists(os.path.join(src, leg, "k_kernel_stats.csv")):
         continue
     shutil.copy(os.path.join(src, leg, "k_kernel_stats.csv"), os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, leg)))
