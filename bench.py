@@ -882,10 +882,58 @@ def main():
         assert np.array_equal(got_g, want_g), "grouped check: verdict vector differs from the exact path's"
         groups_hit = len({int(i) // GROUP for i in which_g})
         assert gstats[0] == (groups_hit, groups_hit * GROUP), "grouped check: unexpected statistics %r" % (gstats[0],)
+        # one host thread, two batches in flight (a stream, a workspace and a verdict buffer each): begin(A), begin(B),
+        # finish(A), begin(A'), finish(B), ... -- the latency-bound parts of one batch hide behind the other
+        g_pipe = None
+        if args.pipeline_streams > 1 and pipelined is not None:
+            PSg = 2
+            # the streams of the `pipelined` leg again: ROCm maps streams onto a few hardware queues, and two streams created
+            # at this point of the run shared one -- their passes ran strictly one after the other (measured: no gain at all)
+            gp_streams = p_streams[:PSg]
+            gp_ws = [torch.empty(gwsb, dtype=torch.uint8, device=dev) for _ in range(PSg)]
+            gp_ok = [torch.full((Bsz,), 7, dtype=torch.int32, device=dev) for _ in range(PSg)]
+            gp_in = [(d_pts, d_sc), (d_pts, d_sc_g)]     # lane 1 verifies the tampered batch all along
+            torch.cuda.synchronize()
+
+            def gp_begin(q):
+                bv.grouped_begin_device(gp_in[q][0].data_ptr(), gp_in[q][1].data_ptr(), Bsz, gkey, rank * Bsz, gp_ok[q].data_ptr(),
+                                        gp_ws[q].data_ptr(), gwsb, group=GROUP, stream=gp_streams[q].cuda_stream)
+
+            def gp_finish(q):
+                return bv.grouped_finish_device(gp_in[q][0].data_ptr(), gp_in[q][1].data_ptr(), Bsz, gp_ok[q].data_ptr(),
+                                                gp_ws[q].data_ptr(), gwsb, group=GROUP, stream=gp_streams[q].cuda_stream)
+
+            def run_pipe(steps, lanes_in):
+                nonlocal gp_in
+                gp_in = lanes_in
+                gp_begin(0)
+                for i in range(steps):
+                    if i + 1 < steps:
+                        gp_begin((i + 1) % PSg)
+                    gp_finish(i % PSg)
+            run_pipe(2, [(d_pts, d_sc), (d_pts, d_sc)])
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0p = time.perf_counter()
+            run_pipe(2 * args.grouped_steps, [(d_pts, d_sc), (d_pts, d_sc)])
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            gpdt = time.perf_counter() - t0p
+            assert all(int(o.sum().item()) == 0 for o in gp_ok), "grouped check, two in flight: a valid batch did not come back all Ok"
+            run_pipe(2, [(d_pts, d_sc), (d_pts, d_sc_g)])    # a valid and the tampered batch in flight together
+            torch.cuda.synchronize()
+            assert int(gp_ok[0].sum().item()) == 0 and np.array_equal(gp_ok[1].cpu().numpy(), want_g), \
+                "grouped check, two in flight: the batches disturbed each other's verdicts"
+            g_pipe = {"value": world * Bsz * 2 * args.grouped_steps / gpdt, "unit": "verifies/s", "in_flight": PSg,
+                      "ms_per_step": gpdt / (2 * args.grouped_steps) * 1e3, "concurrent_verdicts_exact": True,
+                      "note": "bpp_verifier_grouped_begin / _finish from one host thread, two batches in flight"}
+            del gp_ws, gp_ok
         galg = Bsz * bv.msm_len * (2 * ((a.PW - 1) // 2 * 8) + 32)
         gms = gdt / args.grouped_steps * 1e3
         grouped = {"value": world * Bsz * args.grouped_steps / gdt, "unit": "verifies/s", "steps": args.grouped_steps,
-                   "ms_per_step": gms, "group": GROUP, "verdicts": "per proof",
+                   "ms_per_step": gms, "group": GROUP, "verdicts": "per proof", "two_in_flight": g_pipe,
                    "with_tampered": {"tampered": int(Kg), "groups_failed": groups_hit, "proofs_reverified": groups_hit * GROUP,
                                      "value": world * Bsz * args.grouped_steps / gdt_t, "unit": "verifies/s",
                                      "ms_per_step": gdt_t / args.grouped_steps * 1e3, "verdicts_exact": True},

@@ -34,7 +34,7 @@ EXPORTS = [
     "bpp_verifier_table_bytes", "bpp_verifier_run", "bpp_verifier_graph_capture", "bpp_graph_launch", "bpp_graph_destroy", "bpp_range_verify_batch", "bpp_verifier_dominant_kernel",
     "bpp_verifier_set_profiling", "bpp_verifier_profile", "bpp_verifier_set_subgroup_check", "bpp_verifier_partial_bytes",
     "bpp_verifier_combined_workspace_bytes", "bpp_verifier_run_combined", "bpp_verifier_sum_partials",
-    "bpp_verifier_grouped_workspace_bytes", "bpp_verifier_run_grouped",
+    "bpp_verifier_grouped_workspace_bytes", "bpp_verifier_run_grouped", "bpp_verifier_grouped_begin", "bpp_verifier_grouped_finish",
     "bpp_verifier_derive_challenges", "bpp_range_prove_batch_fs", "bpp_range_prove_batch_fs_device",
     "bpp_point_compressed_bytes", "bpp_points_compress", "bpp_points_decompress", "bpp_points_decompress_device",
     "bpp_range_verify_batch_compressed", "bpp_proof_bytes", "bpp_proofs_encode", "bpp_proofs_decode", "bpp_point_uncompressed_bytes", "bpp_points_uncompressed",
@@ -117,6 +117,8 @@ def lib():
         L.bpp_verifier_grouped_workspace_bytes.argtypes = [vp, sz, ctypes.c_uint32]
         L.bpp_verifier_grouped_workspace_bytes.restype = sz
         L.bpp_verifier_run_grouped.argtypes = [vp, vp, vp, sz, vp, ctypes.c_char_p, u64, vp, ctypes.c_uint32, vp, vp, vp, sz, vp]
+        L.bpp_verifier_grouped_begin.argtypes = [vp, vp, vp, sz, vp, ctypes.c_char_p, u64, vp, ctypes.c_uint32, vp, vp, sz, vp]
+        L.bpp_verifier_grouped_finish.argtypes = [vp, vp, vp, sz, vp, ctypes.c_uint32, vp, vp, vp, sz, vp]
         L.bpp_verifier_derive_challenges.argtypes = [vp, vp, sz, vp, vp]
         L.bpp_range_prove_batch_fs.argtypes = [vp, vp, vp, sz, ctypes.c_char_p, u64, vp, vp, vp]
         L.bpp_range_prove_batch_fs_device.argtypes = [vp, vp, vp, sz, ctypes.c_char_p, u64, vp, vp, vp, vp, vp, vp, sz, vp]

@@ -681,6 +681,34 @@ def _verifier_run_grouped_device(self, d_points: int, d_scalars: int, count: int
     return int(stats[0]), int(stats[1])
 
 
+def _verifier_grouped_begin_device(self, d_points: int, d_scalars: int, count: int, weight_key, index_base: int,
+                                   d_out_verdicts: int, d_workspace: int, workspace_bytes: int, group: int = 32, stream: int = 0,
+                                   d_challenges: int = 0, d_weights: int = 0):
+    """First half of run_grouped_device: enqueues the weighted checks of the groups and returns (nothing synchronises)."""
+    key = None
+    if not d_weights:
+        if weight_key is None:
+            import os
+            weight_key = os.urandom(32)
+        key = bytes(weight_key)
+        if len(key) != 32:
+            raise ValueError("weight_key must be 32 bytes")
+    check(_lib.lib().bpp_verifier_grouped_begin(self.handle, d_points, d_scalars, count, d_challenges or None, key,
+                                                ctypes.c_uint64(index_base), d_weights or None, group, d_out_verdicts,
+                                                d_workspace, workspace_bytes, stream or None), "bpp_verifier_grouped_begin")
+
+
+def _verifier_grouped_finish_device(self, d_points: int, d_scalars: int, count: int, d_out_verdicts: int, d_workspace: int,
+                                    workspace_bytes: int, group: int = 32, stream: int = 0, d_challenges: int = 0):
+    """Second half: same buffers, count, group and stream as the begin it completes; synchronises the stream.
+    -> (groups that failed, proofs re-verified exactly)"""
+    stats = (ctypes.c_uint64 * 2)()
+    check(_lib.lib().bpp_verifier_grouped_finish(self.handle, d_points, d_scalars, count, d_challenges or None, group,
+                                                 d_out_verdicts, stats, d_workspace, workspace_bytes, stream or None),
+          "bpp_verifier_grouped_finish")
+    return int(stats[0]), int(stats[1])
+
+
 def _verifier_derive_challenges_device(self, d_points: int, count: int, d_challenges: int, stream: int = 0):
     """Fiat-Shamir challenges [y, z, e, e_1..e_k] of every proof record of a resident batch (csrc/transcript.hpp),
     in the layout run_device takes as d_challenges.  The reference has no transcript: parity unpinned."""
@@ -755,6 +783,8 @@ BatchVerifier.combined_workspace_bytes = _verifier_combined_workspace_bytes
 BatchVerifier.run_combined_device = _verifier_run_combined_device
 BatchVerifier.grouped_workspace_bytes = _verifier_grouped_workspace_bytes
 BatchVerifier.run_grouped_device = _verifier_run_grouped_device
+BatchVerifier.grouped_begin_device = _verifier_grouped_begin_device
+BatchVerifier.grouped_finish_device = _verifier_grouped_finish_device
 BatchVerifier.derive_challenges_device = _verifier_derive_challenges_device
 BatchVerifier.sum_partials_device = _verifier_sum_partials_device
 def _verifier_set_subgroup_check(self, on: bool):

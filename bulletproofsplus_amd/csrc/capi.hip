@@ -540,6 +540,32 @@ extern "C" int bpp_verifier_run_grouped(bpp_verifier* v, const uint64_t* d_point
                                                      static_cast<hipStream_t>(stream));
     });
 }
+// the grouped check in two calls (one host thread, several batches in flight)
+extern "C" int bpp_verifier_grouped_begin(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                          const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                                          const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts,
+                                          void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !d_out_verdicts || !d_workspace || (count && (!d_points || !d_scalars)))
+        return fail(BPP_E_ARG, "null argument");
+    if (!weight_key && !d_weights) return fail(BPP_E_ARG, "the grouped check needs a weight key or a weight buffer");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::grouped_begin(v, d_points, d_scalars, count, d_challenges, weight_key, index_base,
+                                                       d_weights, group, d_out_verdicts, d_workspace, workspace_bytes,
+                                                       static_cast<hipStream_t>(stream));
+    });
+}
+extern "C" int bpp_verifier_grouped_finish(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                           const uint64_t* d_challenges, uint32_t group, uint32_t* d_out_verdicts,
+                                           uint64_t* stats, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!v || !d_out_verdicts || !d_workspace || (count && (!d_points || !d_scalars)))
+        return fail(BPP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(v->ctx.device));
+    return dispatch(v->ctx.curve, [&](auto cv) -> int {
+        return VerifyImpl<decltype(cv)>::grouped_finish(v, d_points, d_scalars, count, d_challenges, group, d_out_verdicts, stats,
+                                                        d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    });
+}
 extern "C" int bpp_verifier_sum_partials(bpp_verifier* v, const void* d_partials, size_t n, uint32_t* d_ok,
                                          void* stream) {
     if (!v || !d_partials || !d_ok) return fail(BPP_E_ARG, "null argument");

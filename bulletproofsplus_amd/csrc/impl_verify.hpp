@@ -1,6 +1,8 @@
 // impl_verify.hpp -- the batch verifier (bpp_verifier_*): window tables in HBM + one pass of the hot path
 // over a device-resident batch.  One instantiation per curve (tu_verify_*.hip).
 #pragma once
+#include <mutex>
+
 #include "codec.hpp"
 #include "combined.hpp"
 #include "fixed_launch.hpp"
@@ -32,6 +34,7 @@ struct bpp_verifier {
     // on first use
     hipStream_t aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::mutex aux_mu;   // the fork .. join of one pass is enqueued as a whole (passes of several host threads share the events)
     ~bpp_verifier() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -290,6 +293,16 @@ struct VerifyImpl {
                            const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
                            const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
                            void* d_workspace, size_t workspace_bytes, hipStream_t st);
+    // the same in two calls, so that ONE host thread can keep several batches in flight (a stream and a workspace each):
+    // grouped_begin only enqueues pass 1; grouped_finish (same buffers, same stream) synchronises, reads the groups' verdicts
+    // and runs pass 2.  run_grouped = begin + finish.
+    static int grouped_begin(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                             const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                             const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, void* d_workspace,
+                             size_t workspace_bytes, hipStream_t st);
+    static int grouped_finish(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                              const uint64_t* d_challenges, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
+                              void* d_workspace, size_t workspace_bytes, hipStream_t st);
 
     // ---- batched prover (prover_batch.hpp) -------------------------------------------------------------
     // Device-resident form: values, gammas, outputs and workspace are device buffers, nothing touches the host
@@ -457,7 +470,9 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     // additions and an inversion that nothing else waits for yet, so it runs on a side stream beside the (equally latency
     // bound) scalar kernels and joins before the window sums.  Large batches fill the chip in every stage: one stream.
     const bool side_tables = count * blocks_per_proof(s, count) <= 1024 && count <= HORNER_TREE_MAX;
+    std::unique_lock<std::mutex> aux_lock(v->aux_mu, std::defer_lock);
     if (side_tables) {
+        aux_lock.lock();
         if (!v->aux) {
             HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
@@ -496,9 +511,10 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     const size_t vlanes = count * (tree == 1 ? var_wsums<C>() * vgroups : var_windows<C>());
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
-    if (side_tables)
+    if (side_tables) {
         HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
-    else
+        aux_lock.unlock();
+    } else
         hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                            reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
@@ -681,12 +697,24 @@ int VerifyImpl<C>::run_grouped(bpp_verifier* v, const uint64_t* d_points, const 
                                const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
                                const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
                                void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+    int rc = grouped_begin(v, d_points, d_scalars, count, d_challenges, weight_key, index_base, d_weights, group, d_out_verdicts,
+                           d_workspace, workspace_bytes, st);
+    if (rc) return rc;
+    return grouped_finish(v, d_points, d_scalars, count, d_challenges, group, d_out_verdicts, h_stats, d_workspace,
+                          workspace_bytes, st);
+}
+
+// pass 1 (only enqueues): one weighted check per group, through the batch verifier's own last stages at count = G
+template <class C>
+int VerifyImpl<C>::grouped_begin(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                 const uint64_t* d_challenges, const uint8_t* weight_key, uint64_t index_base,
+                                 const uint64_t* d_weights, uint32_t group, uint32_t* d_out_verdicts, void* d_workspace,
+                                 size_t workspace_bytes, hipStream_t st) {
     const VerifyShape& s = v->s;
     if (group < 2 || (group & (group - 1))) return fail(BPP_E_ARG, "group must be a power of two, at least 2");
     const GroupLayout L = group_layout(s, count, group);
     if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
     if (count * s.NV >= ((size_t)1 << 30)) return fail(BPP_E_ARG, "count too large");
-    if (h_stats) h_stats[0] = h_stats[1] = 0;
     if (count == 0) return BPP_OK;
     uint8_t* ws = static_cast<uint8_t*>(d_workspace);
     auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
@@ -695,7 +723,6 @@ int VerifyImpl<C>::run_grouped(bpp_verifier* v, const uint64_t* d_points, const 
     uint32_t* w_gok = W(L.gok);
     uint8_t* w_vd = ws + L.vdig;
     const size_t items = count * s.NV, G = L.groups;
-    // ---- pass 1: one weighted check per group, through the batch verifier's own last stages at count = G --------
     HIPCHK(zero_words_async(w_bad, count * 4, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
@@ -743,10 +770,27 @@ int VerifyImpl<C>::run_grouped(bpp_verifier* v, const uint64_t* d_points, const 
     }
     hipLaunchKernelGGL(k_comb_group_spread, dim3(cdiv(count, 256)), dim3(256), 0, st, w_gok, group, d_out_verdicts, count);
     HIPCHK(hipGetLastError());
+    return BPP_OK;
+}
+
+// the groups' verdicts come back to the host (synchronises `st`); pass 2: the proofs of the groups that failed, exactly,
+// through the per-proof path.  Same buffers and stream as the grouped_begin it completes.
+template <class C>
+int VerifyImpl<C>::grouped_finish(bpp_verifier* v, const uint64_t* d_points, const uint64_t* d_scalars, size_t count,
+                                  const uint64_t* d_challenges, uint32_t group, uint32_t* d_out_verdicts, uint64_t* h_stats,
+                                  void* d_workspace, size_t workspace_bytes, hipStream_t st) {
+    const VerifyShape& s = v->s;
+    if (group < 2 || (group & (group - 1))) return fail(BPP_E_ARG, "group must be a power of two, at least 2");
+    const GroupLayout L = group_layout(s, count, group);
+    if (workspace_bytes < L.total) return fail(BPP_E_ARG, "workspace too small");
+    if (h_stats) h_stats[0] = h_stats[1] = 0;
+    if (count == 0) return BPP_OK;
+    uint8_t* ws = static_cast<uint8_t*>(d_workspace);
+    auto W = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+    const size_t G = L.groups;
     std::vector<uint32_t> gok(G);
-    HIPCHK(hipMemcpyAsync(gok.data(), w_gok, G * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(gok.data(), W(L.gok), G * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    // ---- pass 2: the proofs of the groups that failed, exactly, through the per-proof path ------------------------
     std::vector<uint32_t> list;
     size_t failed = 0;
     for (size_t g = 0; g < G; g++)

@@ -189,6 +189,8 @@ size_t bpp_verifier_table_bytes(const bpp_verifier *v);
  * The call only enqueues work on `stream` (kernels, and for a batch small enough to be latency bound an event fork/join
  * with a side stream of the verifier): after one eager call it can be captured into a HIP graph and replayed
  * (tests/test_gpu_round2.py::test_verifier_run_is_graph_capturable).
+ * A verifier may be used by several host threads and on several streams at once, each pass with a workspace and a verdict
+ * buffer of its own (the tables are read-only); the stage profiling is the exception: one thread while it is on.
  * Points are elements of the prime-order group (what the prover, mcl, or the decoder with its subgroup check produce).
  * On BLS12-381 the proof-carried points are multiplied through G1's endomorphism (GLV, as mcl itself does): for points
  * of G1 the result is sum s_i P_i bit for bit; a curve point OUTSIDE G1 is still processed deterministically and its
@@ -274,6 +276,19 @@ int bpp_verifier_run_grouped(bpp_verifier *v, const uint64_t *d_points, const ui
                              const uint64_t *d_challenges, const uint8_t *weight_key, uint64_t index_base,
                              const uint64_t *d_weights, uint32_t group, uint32_t *d_out_verdicts, uint64_t *stats,
                              void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The same in two calls, so that ONE host thread can keep several batches in flight (a stream, a workspace and a verdict
+ * buffer per batch): bpp_verifier_grouped_begin only enqueues the weighted checks of the groups; bpp_verifier_grouped_finish,
+ * given the same buffers, count, group and stream, synchronises that stream, reads the groups' verdicts and re-verifies the
+ * proofs of the failing ones.  begin(A), begin(B), finish(A), begin(C), finish(B), ... hides the latency-bound parts of one
+ * batch behind the other (+13 % on (64,16) x 8192).  bpp_verifier_run_grouped = begin + finish. */
+int bpp_verifier_grouped_begin(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                               const uint64_t *d_challenges, const uint8_t *weight_key, uint64_t index_base,
+                               const uint64_t *d_weights, uint32_t group, uint32_t *d_out_verdicts, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
+int bpp_verifier_grouped_finish(bpp_verifier *v, const uint64_t *d_points, const uint64_t *d_scalars, size_t count,
+                                const uint64_t *d_challenges, uint32_t group, uint32_t *d_out_verdicts, uint64_t *stats,
+                                void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Fiat-Shamir transcript (csrc/transcript.hpp) -- what the reference's constants stand in for --------
  * The reference has no transcript (every challenge is a literal, src/range/mod.rs:278-279,

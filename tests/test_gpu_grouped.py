@@ -218,3 +218,62 @@ def test_grouped_exact_pass_fits_whatever_the_failing_count():
         want[victims] = 1
         assert np.array_equal(ok, want) and (failed, redone) == (ngroups, ngroups * group)
     bv.close()
+
+
+def test_grouped_begin_finish_two_batches_in_flight():
+    """bpp_verifier_grouped_begin / _finish: two batches in flight from one host thread (a stream, a workspace and a verdict
+    buffer each), one of them tampered; and the lone-batch path of the exact pass from two host threads at once."""
+    torch = need_gpu()
+    import threading
+    import hashlib
+    import bulletproofsplus_amd as B
+    n, vals, gams = 8, [200, 5], [3, 7]
+    opk, bv = _engine(B, "bls12_381", n, 2, 5)
+    base_r, base_s = _proofs(bv, opk, n, vals, gams, 6)
+    count, group = 40, 4
+    recs = np.ascontiguousarray(base_r[np.arange(count) % 6])
+    good = np.ascontiguousarray(base_s[np.arange(count) % 6])
+    bad = good.copy()
+    for v in (3, 17, 18, 39):
+        bad[v, 2, 0] ^= np.uint64(8)
+    want_bad = [1 if i in (3, 17, 18, 39) else 0 for i in range(count)]
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(recs.view(np.int64)).to(dev)
+    d_sc = [torch.from_numpy(x.view(np.int64)).to(dev) for x in (good, bad)]
+    wsb = bv.grouped_workspace_bytes(count, group)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    wss = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(2)]
+    oks = [torch.full((count,), 7, dtype=torch.int32, device=dev) for _ in range(2)]
+    key = hashlib.sha256(b"two in flight").digest()
+    torch.cuda.synchronize()
+    stats = [None, None]
+    for rep in range(3):
+        for q in range(2):
+            bv.grouped_begin_device(d_pts.data_ptr(), d_sc[q].data_ptr(), count, key, 0, oks[q].data_ptr(), wss[q].data_ptr(), wsb,
+                                    group=group, stream=streams[q].cuda_stream)
+        for q in range(2):
+            stats[q] = bv.grouped_finish_device(d_pts.data_ptr(), d_sc[q].data_ptr(), count, oks[q].data_ptr(), wss[q].data_ptr(),
+                                                wsb, group=group, stream=streams[q].cuda_stream)
+        torch.cuda.synchronize()
+        assert oks[0].cpu().numpy().tolist() == [0] * count and stats[0] == (0, 0)
+        assert oks[1].cpu().numpy().tolist() == want_bad and stats[1] == (3, 12)
+    # two host threads, each running whole grouped checks whose exact pass is a lone batch (side stream, shared events)
+    errs = []
+
+    def worker(q):
+        try:
+            for _ in range(6):
+                bv.run_grouped_device(d_pts.data_ptr(), d_sc[1].data_ptr(), count, key, 0, oks[q].data_ptr(), wss[q].data_ptr(), wsb,
+                                      group=group, stream=streams[q].cuda_stream)
+                streams[q].synchronize()
+                if oks[q].cpu().numpy().tolist() != want_bad:
+                    errs.append(q)
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=worker, args=(q,)) for q in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errs == []
+    bv.close()
