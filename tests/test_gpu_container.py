@@ -304,3 +304,53 @@ def test_container_version_2_on_device(cname, cid):
     a_e = B.Arith.init("ed25519")
     assert B.uncompressed_bytes(a_e) == 0 and B.proof_bytes(a_e, n, m, 2) == 0
     bv.close()
+
+
+@pytest.mark.parametrize("cname,cid", [("bls12_381", 0), ("secp256k1", 1), ("ed25519", 2)])
+def test_container_mutations_statuses_match_restatement(cname, cid):
+    """Random byte mutations of valid containers (1-3 bytes each, anywhere: header, point encodings, scalars): the device
+    decoder's FormatError verdict equals the restatement's (pyref.decode_proof is None), container by container; a mutated
+    container that still parses fails verification (status 1); nothing else changes its neighbours' statuses."""
+    need_gpu()
+    import random
+    import bulletproofsplus_amd as B
+    c = P.CURVES[cname]
+    G = P.make_group(cname, False)
+    n, m, count = 4, 2, 160
+    a = B.Arith.init(cname)
+    bv = B.BatchVerifier(B.PublicKey.new(a, n * m), n, m, window_bits=4)
+    base = 8
+    vals = [[(5 * i + j) % 16 for j in range(m)] for i in range(base)]
+    gams = [[2 + i + j for j in range(m)] for i in range(base)]
+    pts, scs, V = bv.prove_batch(vals, gams)
+    blobs8 = B.encode_proofs(a, n, m, pts, scs)
+    comm8 = B.compress_points(a, V.reshape(-1, a.PW)).reshape(base, m, -1)
+    idx = np.arange(count) % base
+    blobs, comm = np.ascontiguousarray(blobs8[idx]), np.ascontiguousarray(comm8[idx])
+    assert bv.verify_serialized(blobs, comm).tolist() == [0] * count
+    rng = random.Random(1234 + cid)
+    mutated = blobs.copy()
+    touched = set()
+    for i in range(count):
+        if i % 4 == 3:
+            continue                       # every fourth container stays valid
+        touched.add(i)
+        for _ in range(rng.randint(1, 3)):
+            pos = rng.randrange(blobs.shape[1])
+            mutated[i, pos] ^= 1 << rng.randrange(8)
+        if np.array_equal(mutated[i], blobs[i]):          # two flips cancelled
+            mutated[i, -1] ^= 1
+    got = bv.verify_serialized(mutated, comm).tolist()
+    n_format = 0
+    for i in range(count):
+        if i not in touched:
+            assert got[i] == 0, i
+            continue
+        parsed = P.decode_proof(c, G, n, m, bytes(mutated[i]))
+        if parsed is None:
+            n_format += 1
+            assert got[i] == 2, (i, got[i])
+        else:
+            assert got[i] == 1, (i, got[i])
+    assert 10 < n_format < len(touched)        # both kinds occurred
+    bv.close()
