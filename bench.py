@@ -1224,8 +1224,46 @@ def main():
                 pgstep(0, d_bl_q)
                 torch.cuda.synchronize()
                 assert np.array_equal(d_ok_p.cpu().numpy().astype(np.int64), want_q), "production leg, grouped: status vector differs"
+                # two host threads (the calls release the interpreter lock), each with its own stream, workspace and status
+                # buffer: what two worker threads of a service sharing the verifier get
+                two_threads = None
+                if pipelined is not None:
+                    import threading
+                    t_ws = [d_gws_p, torch.empty(gwsb_p, dtype=torch.uint8, device=dev)]
+                    t_ok = [torch.full((pbatch,), 7, dtype=torch.int32, device=dev) for _ in range(2)]
+                    t_err = []
+                    reps_t = max(2, args.production_steps)
+
+                    def t_worker(q, reps):
+                        try:
+                            for _ in range(reps):
+                                bv_p.verify_serialized_grouped_device(d_bl_p.data_ptr(), d_cm_p.data_ptr(), pbatch, t_ok[q].data_ptr(),
+                                                                      t_ws[q].data_ptr(), gwsb_p, gkey_p, rank * pbatch, args.group,
+                                                                      p_streams[q].cuda_stream, transcript=True)
+                        except Exception as e:   # noqa: BLE001
+                            t_err.append(repr(e))
+                    torch.cuda.synchronize()
+                    for q in range(2):
+                        t_worker(q, 1)
+                    torch.cuda.synchronize()
+                    if dist is not None:
+                        dist.barrier()
+                    ths = [threading.Thread(target=t_worker, args=(q, reps_t)) for q in range(2)]
+                    t0t = time.perf_counter()
+                    for th in ths:
+                        th.start()
+                    for th in ths:
+                        th.join()
+                    torch.cuda.synchronize()
+                    if dist is not None:
+                        dist.barrier()
+                    tdt = time.perf_counter() - t0t
+                    assert not t_err and all(int(o.sum().item()) == 0 for o in t_ok), "production leg, two threads: %r" % (t_err,)
+                    two_threads = {"value": world * pbatch * 2 * reps_t / tdt, "unit": "verifies/s",
+                                   "ms_per_step": tdt / (2 * reps_t) * 1e3, "threads": 2}
+                    del t_ws, t_ok
                 grouped_p = {"value": world * pbatch * args.production_steps / pgdt, "unit": "verifies/s",
-                             "ms_per_step": pgdt / args.production_steps * 1e3, "group": args.group,
+                             "ms_per_step": pgdt / args.production_steps * 1e3, "group": args.group, "two_threads": two_threads,
                              "status_check": {"tampered": int(Kq), "statuses_exact": True, "groups_failed": gst_p[0][0],
                                               "proofs_reverified": gst_p[0][1]},
                              "note": "bpp_range_verify_batch_serialized_grouped_device: decode + challenge derivation + one weighted "
