@@ -466,10 +466,14 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(npts, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, npts, s.NV, v->check_subgroup ? 1u : 0u);
     HIPCHK(mark(2 * BPP_STAGE_FROM_WIRE + 1, st));
-    // Lone batches (below): the tables of the proof points need the points only, not the scalars -- a chain of seven
-    // additions and an inversion that nothing else waits for yet, so it runs on a side stream beside the (equally latency
-    // bound) scalar kernels and joins before the window sums.  Large batches fill the chip in every stage: one stream.
-    const bool side_tables = count * blocks_per_proof(s, count) <= 1024 && count <= HORNER_TREE_MAX;
+    // The tables of the proof points need the points only, not the scalars -- a chain of seven additions and an inversion
+    // that nothing else waits for yet -- so they are built on a side stream beside the scalar kernels and join before the
+    // window sums.  For a lone batch both are latency bound; for a large one k_vs_prepare is (one lane per proof: 128 waves
+    // for 8 192 proofs, 0.2 ms with the chip nearly empty) and the tables fill what it leaves.
+#ifndef BPP_SIDE_TABLES_ALWAYS
+#define BPP_SIDE_TABLES_ALWAYS 1
+#endif
+    const bool side_tables = BPP_SIDE_TABLES_ALWAYS || (count * blocks_per_proof(s, count) <= 1024 && count <= HORNER_TREE_MAX);
     std::unique_lock<std::mutex> aux_lock(v->aux_mu, std::defer_lock);
     if (side_tables) {
         aux_lock.lock();
