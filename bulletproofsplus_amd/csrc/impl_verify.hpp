@@ -730,6 +730,17 @@ int VerifyImpl<C>::grouped_begin(bpp_verifier* v, const uint64_t* d_points, cons
     HIPCHK(zero_words_async(w_bad, count * 4, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
+    // the proof points' tables need the points only: on the verifier's side stream, beside the scalar kernels (as in run())
+    std::unique_lock<std::mutex> aux_lock(v->aux_mu);
+    if (!v->aux) {
+        HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(v->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(v->aux, v->ev_fork, 0));
+    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, v->aux, w_pts, w_vt, W(L.vscr), items);
+    HIPCHK(hipEventRecord(v->ev_join, v->aux));
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     {
@@ -751,7 +762,8 @@ int VerifyImpl<C>::grouped_begin(bpp_verifier* v, const uint64_t* d_points, cons
     const uint32_t per = tree == 1 ? var_wsums<C>() : var_windows<C>();   // window sums per proof, in the layout the Horner form reads
     hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
-    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, W(L.vscr), items);
+    HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
+    aux_lock.unlock();
     const size_t vlanes = count * per;
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes, tree == 1 ? 1u : 0u, 1u);
