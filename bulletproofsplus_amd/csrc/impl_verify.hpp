@@ -129,6 +129,29 @@ struct VerifyImpl {
         const bool small_job = (double)count * ((double)s.NF * s.W / 7.0e9 + 9.2e-8) < 2.0e-3;
         return count <= HORNER_TREE_MAX ? 1u : (small_job ? 2u : 0u);
     }
+    // The proof points' tables (k_var_tables) need the points but not the scalars: fork_tables builds them on the verifier's
+    // side stream, beside whatever the caller enqueues next on `st` (the scalar kernels); join_tables makes `st` wait for them
+    // (before k_var_windows).  The fork .. join of one pass is enqueued under the verifier's mutex: the side stream and its
+    // two events are shared by the passes of every stream and host thread.
+    static int fork_tables(bpp_verifier* v, hipStream_t st, const uint32_t* w_pts, uint32_t* w_vt, uint32_t* w_vscr, size_t items,
+                           std::unique_lock<std::mutex>& lock) {
+        lock = std::unique_lock<std::mutex>(v->aux_mu);
+        if (!v->aux) {
+            HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(v->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(v->aux, v->ev_fork, 0));
+        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, v->aux, w_pts, w_vt, w_vscr, items);
+        HIPCHK(hipEventRecord(v->ev_join, v->aux));
+        return BPP_OK;
+    }
+    static int join_tables(bpp_verifier* v, hipStream_t st, std::unique_lock<std::mutex>& lock) {
+        HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
+        lock.unlock();
+        return BPP_OK;
+    }
     static int finish(bpp_verifier* v, uint8_t* ws, const WsLayout& L, size_t count, const uint32_t* w_sc,
                       const uint32_t* w_vw, const uint32_t* w_bad, uint32_t* d_ok, uint32_t* d_out_result, uint32_t tree,
                       bool lone, hipStream_t st, hipEvent_t* ev);
@@ -474,19 +497,10 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
 #define BPP_SIDE_TABLES_ALWAYS 1
 #endif
     const bool side_tables = BPP_SIDE_TABLES_ALWAYS || (count * blocks_per_proof(s, count) <= 1024 && count <= HORNER_TREE_MAX);
-    std::unique_lock<std::mutex> aux_lock(v->aux_mu, std::defer_lock);
+    std::unique_lock<std::mutex> aux_lock;
     if (side_tables) {
-        aux_lock.lock();
-        if (!v->aux) {
-            HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
-        }
-        HIPCHK(hipEventRecord(v->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(v->aux, v->ev_fork, 0));
-        hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, v->aux, w_pts, w_vt,
-                           reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
-        HIPCHK(hipEventRecord(v->ev_join, v->aux));
+        int rc_f = fork_tables(v, st, w_pts, w_vt, reinterpret_cast<uint32_t*>(ws + L.vscr), npts, aux_lock);
+        if (rc_f) return rc_f;
     }
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
@@ -516,8 +530,8 @@ int VerifyImpl<C>::run(bpp_verifier* v, const uint64_t* d_points, const uint64_t
     HIPCHK(mark(2 * BPP_STAGE_VAR_MSM, st));
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(npts, 256)), dim3(256), 0, st, s, w_sc, w_vd, npts, 0u);
     if (side_tables) {
-        HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
-        aux_lock.unlock();
+        int rc_j = join_tables(v, st, aux_lock);
+        if (rc_j) return rc_j;
     } else
         hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(npts, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt,
                            reinterpret_cast<uint32_t*>(ws + L.vscr), npts);
@@ -654,6 +668,11 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     HIPCHK(zero_words_async(w_cs, (size_t)s.N * 32, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
+    std::unique_lock<std::mutex> aux_lock;
+    {
+        int rc_f = fork_tables(v, st, w_pts, w_vt, w_vscr, items, aux_lock);
+        if (rc_f) return rc_f;
+    }
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     {
@@ -672,7 +691,10 @@ int VerifyImpl<C>::run_combined(bpp_verifier* v, const uint64_t* d_points, const
     // proof-carried points: weighted scalars -> per-proof Straus window sums -> summed across proofs per window
     hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
-    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, w_pts, w_vt, w_vscr, items);
+    {
+        int rc_j = join_tables(v, st, aux_lock);
+        if (rc_j) return rc_j;
+    }
     const size_t vlanes = count * var_wsums<C>();
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes, 1u, 1u);
@@ -730,17 +752,11 @@ int VerifyImpl<C>::grouped_begin(bpp_verifier* v, const uint64_t* d_points, cons
     HIPCHK(zero_words_async(w_bad, count * 4, st));
     hipLaunchKernelGGL(k_points_from_wire<C>, dim3(cdiv(items, 128)), dim3(128), 0, st,
                        reinterpret_cast<const uint32_t*>(d_points), w_pts, w_bad, items, s.NV, v->check_subgroup ? 1u : 0u);
-    // the proof points' tables need the points only: on the verifier's side stream, beside the scalar kernels (as in run())
-    std::unique_lock<std::mutex> aux_lock(v->aux_mu);
-    if (!v->aux) {
-        HIPCHK(hipStreamCreateWithFlags(&v->aux, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+    std::unique_lock<std::mutex> aux_lock;
+    {
+        int rc_f = fork_tables(v, st, w_pts, w_vt, W(L.vscr), items, aux_lock);
+        if (rc_f) return rc_f;
     }
-    HIPCHK(hipEventRecord(v->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(v->aux, v->ev_fork, 0));
-    hipLaunchKernelGGL(k_var_tables<C>, dim3(cdiv(items, VAR_BLOCK)), dim3(VAR_BLOCK), 0, v->aux, w_pts, w_vt, W(L.vscr), items);
-    HIPCHK(hipEventRecord(v->ev_join, v->aux));
     const uint32_t* ch = d_challenges ? reinterpret_cast<const uint32_t*>(d_challenges) : v->challenges.u32();
     const uint32_t ch_stride = d_challenges ? (3 + s.k) * 8 : 0;
     {
@@ -762,8 +778,10 @@ int VerifyImpl<C>::grouped_begin(bpp_verifier* v, const uint64_t* d_points, cons
     const uint32_t per = tree == 1 ? var_wsums<C>() : var_windows<C>();   // window sums per proof, in the layout the Horner form reads
     hipLaunchKernelGGL(k_comb_var_scalars<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_sc, w_wt, w_vs, items);
     hipLaunchKernelGGL(k_var_digits<C>, dim3(cdiv(items, 256)), dim3(256), 0, st, s, w_vs, w_vd, items, 1u);
-    HIPCHK(hipStreamWaitEvent(st, v->ev_join, 0));
-    aux_lock.unlock();
+    {
+        int rc_j = join_tables(v, st, aux_lock);
+        if (rc_j) return rc_j;
+    }
     const size_t vlanes = count * per;
     hipLaunchKernelGGL(k_var_windows<C>, dim3(cdiv(vlanes, VAR_BLOCK)), dim3(VAR_BLOCK), 0, st, s, w_vd, w_vt, w_vw,
                        vlanes, tree == 1 ? 1u : 0u, 1u);
