@@ -72,7 +72,9 @@ def loop_peaks(curve):
     for cand in ("ubench_r03.json", "ubench_r02.json", "ubench_r01_final.json"):
         try:
             uj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-            key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}.get(curve)
+            key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp", "ed25519": "xyzz_madd_lazy_ed"}.get(curve)
+            if key is not None and key not in uj and key.replace("_lazy", "") not in uj:
+                key = None
             if key is None:
                 return None, uj["v_mad_u64_u32"]["Gops"] / 1e3, "profiles/" + cand
             if key not in uj:

@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(128, 2) k_xyzz_lazy(uint32_t* out, uint32_t se
     fe_cond_sub_p(p.y);
     Xyzz<C> xa = xyzz_madd(xyzz_dbl_aff(g), g);
     for (int it = 0; it < iters; it++) xyzz_madd_lazy(xa, p, (it & 1) != 0);
-    if (xa.X.l[0] == 0x3fffffff && xa.Y.l[1] == 0x12345) out[0] = xa.ZZ.l[2];
+    const Jac<C> r = xyzz_to_jac(xa);
+    if (r.X.l[0] == 0x3fffffff && r.Y.l[1] == 0x12345) out[0] = r.Z.l[2];
 }
 
 // one dependent v_mad_u64_u32 chain per wave, NCH independent chains: issue-to-issue latency of the multiplier
@@ -206,6 +207,7 @@ int main() {
     grp("xyzz_madd_secp", k_xyzz<Secp256k1>, 300, 8);
     grp("xyzz_madd_lazy_bls", k_xyzz_lazy<Bls12381>, 300, 8);
     grp("xyzz_madd_lazy_secp", k_xyzz_lazy<Secp256k1>, 300, 8);
+    grp("xyzz_madd_lazy_ed", k_xyzz_lazy<Ed25519>, 300, 8);   // the unified extended-coordinate addition of k_fixed_msm<Ed25519>
     grp("jac_madd_secp", k_group<Secp256k1, 0>, 300, 8);
     grp("jac_dbl_secp", k_group<Secp256k1, 1>, 300, 8);
     printf(" \"end\": 0}\n");
