@@ -1379,7 +1379,7 @@ def main():
             order = MSM_ORDER[mc]
             g_m = B.PublicKey.new(a_m, 0).gh[0]
             fpb = (a_m.PW - 1) // 2 * 8
-            loop_peak = (uj.get({"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}.get(mc, "")) or {}).get("Gops")
+            loop_peak = (uj.get({"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp", "ed25519": "xyzz_madd_lazy_ed"}.get(mc, "")) or {}).get("Gops")
             rows = []
             for lg in args.msm_log2n:
                 N = 1 << lg
@@ -1491,7 +1491,7 @@ def main():
         for cand in ("ubench_r03.json", "ubench_r02.json", "ubench_r01_final.json"):
             try:
                 uj = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp"}[args.curve]
+                key = {"bls12_381": "xyzz_madd_lazy_bls", "secp256k1": "xyzz_madd_lazy_secp", "ed25519": "xyzz_madd_lazy_ed"}[args.curve]
                 if key not in uj:
                     key = key.replace("_lazy", "")
                 add_peak = uj[key]["Gops"]
