@@ -1069,7 +1069,15 @@ __global__ void __launch_bounds__(FIXED_BLOCK, fixed_waves<C>()) k_fixed_msm(Ver
         return;
     }
     // flat grid after the Horner blocks: block = proof * per + part   (`per` blocks share one proof's generators)
+#ifdef BPP_XCD_REMAP   // tuning builds only (DESIGN "XCDs"): the `per` blocks of a proof on ONE XCD -- workgroups go to the 8 XCDs round-robin
+    uint32_t bid = blockIdx.x - horner_blocks;
+    {
+        const uint32_t nb = gridDim.x - horner_blocks;
+        if (nb % 8 == 0 && horner_blocks % 8 == 0) bid = (bid % 8) * (nb / 8) + bid / 8;
+    }
+#else
     const uint32_t bid = blockIdx.x - horner_blocks;
+#endif
     const size_t b = bid / per;
     const uint32_t part = bid % per;
     const uint32_t* sc = scalars + ((b / sel.cnt) * sel.nvp + sel.first + b % sel.cnt) * (size_t)s.N * 8;
